@@ -1,0 +1,221 @@
+/*
+ * sparch_hip.h — C ABI of libsparch_hip.so, the MI355X (gfx950) implementation of
+ * sparch's recurrent spiking-layer training path.
+ *
+ * The reference (thebarnable/sparch) has NO native/FFI interface: its hot path is
+ * eager PyTorch inside Python `for t in range(T)` loops.  Each entry point below
+ * therefore replaces a *group of eager ops* of the reference, cited as
+ * snns.py:LINE (= /root/reference/sparch/models/snns.py) or exp.py:LINE.  The
+ * Python binding a maintainer adds is a ctypes stub; ours lives in
+ * sparch_amd/_capi.py.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator);
+ *     the library never allocates, frees, copies to host or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - tensors are fp32, dense, row-major; (B,T,H) means b-major, h contiguous;
+ *   - return value: 0 = SPARCH_OK, negative = error (nothing was launched);
+ *     sparch_strerror() maps codes to text.  Python maps them to ValueError /
+ *     RuntimeError, the reference's error convention;
+ *   - re-entrant per stream; no global mutable state.
+ *
+ * "kind" of a spiking cell: 0 LIF, 1 adLIF, 2 RLIF, 3 RadLIF
+ *   bit0 = adaptive (w state, beta/a/b), bit1 = recurrent (V).
+ */
+#ifndef SPARCH_HIP_H
+#define SPARCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPARCH_OK 0
+#define SPARCH_EINVAL (-1)      /* bad shape / null pointer / unsupported size        */
+#define SPARCH_EALIGN (-2)      /* pointer or leading dimension not 16-byte aligned   */
+#define SPARCH_EWORKSPACE (-3)  /* workspace too small (see *_workspace_bytes)        */
+#define SPARCH_ELAUNCH (-4)     /* HIP reported a launch error                        */
+#define SPARCH_ETIMEOUT (-5)    /* reported through a status word: in-kernel wait gave up */
+
+#define SPARCH_KIND_LIF 0
+#define SPARCH_KIND_ADLIF 1
+#define SPARCH_KIND_RLIF 2
+#define SPARCH_KIND_RADLIF 3
+
+int sparch_abi_version(void);
+const char* sparch_strerror(int code);
+/* Number of compute units / XCDs the library sizes its persistent grids for. */
+int sparch_device_cus(void);
+
+/* ------------------------------------------------------------------------------------
+ * G1  feed-forward projection  (replaces `self.W(x)` = nn.Linear, snns.py:261/398/533/675/796,
+ *     and its autograd backward).  Hand-written fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs.
+ * ---------------------------------------------------------------------------------- */
+
+/* C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]).  Optional fused column statistics for
+ * BatchNorm: if colstat_ws != NULL it receives per-row-tile partial sums
+ * (2 * ceil(M/128) * N floats: [tile][N] sums then [tile][N] sums of squares) of the
+ * values written to C, to be finished by sparch_bn_finalize().                       */
+int sparch_gemm_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, const float* bias, float* colstat_ws, void* stream);
+
+/* C[M,N] = A[M,K] * B[K,N]          (dX = dWx * W; rec0 = s0 * Vmasked)            */
+int sparch_gemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, void* stream);
+
+/* C[M,N] = A[K,M]^T * B[K,N], contraction over the long K axis (dW = dWx^T * x,
+ * dV = s_prev^T * dWx).  Split-K over `splits` slabs held in `ws`
+ * (sparch_gemm_tn_workspace_bytes), reduced in fixed order => bitwise reproducible.  */
+size_t sparch_gemm_tn_workspace_bytes(int M, int N, int K);
+int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, int zero_diag, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * G2  normalisation on the (M = B*T, H) view  (replaces nn.BatchNorm1d(momentum=0.05) /
+ *     nn.LayerNorm, snns.py:240-243, 264-266).  BatchNorm is folded into a per-column
+ *     (scale, shift) that the cell kernels apply on load.
+ * ---------------------------------------------------------------------------------- */
+
+/* Train: finish the statistics from colstat_ws (n_tiles partial rows, count = M rows,
+ * `dup` = 2 when a bidirectional layer sees every row twice: running_var uses
+ * n = dup*M), write scale = gamma*invstd, shift = beta - mean*scale, save mean/invstd,
+ * update running stats in place (momentum m, unbiased variance).
+ * Eval (training = 0): scale/shift from running stats; colstat_ws ignored.           */
+int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const float* colstat_ws,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int training,
+                       float* scale, float* shift, float* save_mean, float* save_invstd,
+                       void* stream);
+
+/* Column sums of dy and dy*xhat over M rows (xhat = (x-mean)*invstd), partials in ws
+ * (2 * ceil(M/256) * H floats), finished into dgamma[H], dbeta[H].                   */
+size_t sparch_bn_bwd_workspace_bytes(int M, int H);
+int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* x, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, void* ws,
+                         size_t ws_bytes, void* stream);
+/* dx = scale * (dy - dbeta/M - xhat * dgamma/M), in place allowed (dx == dy).        */
+int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x, const float* mean,
+                        const float* invstd, const float* gamma, const float* dgamma,
+                        const float* dbeta, float* dx, void* stream);
+
+/* LayerNorm over H per row: y = (x-mu)*rstd*gamma + beta; saves mu, rstd (M each).    */
+int sparch_layernorm_fwd(int M, int H, const float* x, const float* gamma, const float* beta,
+                         float eps, float* y, float* mu, float* rstd, void* stream);
+/* dx per row; dgamma/dbeta column sums via ws (2*ceil(M/256)*H floats).               */
+int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const float* mu,
+                         const float* rstd, const float* gamma, float* dx, float* dgamma,
+                         float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * G3/G4/G6/G7  spiking cells, time loop inside the kernel  (replaces _lif_cell
+ *     snns.py:282-303, _adlif_cell 419-445, _rlif_cell 554-578, _radlif_cell 696-727,
+ *     SpikeFunctionBoxcar 20-36, the bidirectional flip/cat glue 252-254 / 272-275 and
+ *     nn.Dropout 278, plus their autograd replay).
+ *
+ * Geometry: B = batch, dirs = 1 | 2 (bidirectional), Bp = B*dirs virtual rows.
+ *   Wx      (B,T,H)  raw projection; the cell applies x*scale[h]+shift[h] when scale != NULL.
+ *           Virtual row b' >= B reads Wx[b'-B, T-1-t] (time-flipped copy, never materialised).
+ *   u0,w0,s0 (Bp,H)  random initial states drawn by the host in the reference's order.
+ *   s_out   (B,T,H*dirs)  post-dropout output; direction d lands in features [d*H,(d+1)*H)
+ *           at its ORIGINAL time index (un-flipped), as snns.py:272-275.
+ *   u_save, w_save (Bp,T,H) in cell time order; needed by the backward (NULL => not saved).
+ *   spike_count (H*dirs) uint32: number of spikes surviving dropout per output feature;
+ *           firing rate = count * keep_scale / (B*T)  (snns.py:174 after 278).
+ *   Dropout: keep iff hash(seed, output element index) >= p; kept values scale by 1/(1-p).
+ * ---------------------------------------------------------------------------------- */
+
+/* Non-recurrent kinds (LIF, adLIF): one thread per (row, 4 columns), T-loop in registers. */
+int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
+                    const float* scale, const float* shift, const float* alpha,
+                    const float* beta, const float* a, const float* b, const float* u0,
+                    const float* w0, const float* s0, float theta, float p_drop,
+                    uint64_t seed, float* s_out, float* u_save, float* w_save,
+                    uint32_t* spike_count, void* stream);
+
+/* g_out (B,T,H*dirs) upstream gradient of s_out; g_rate (H*dirs) upstream gradient of the
+ * firing rates (NULL = none).  dWx (Bp,T,H): gradient w.r.t. the normalised projection,
+ * virtual-row order but ORIGINAL time index (so rows b and b+B add elementwise).
+ * dparam_ws: (4,Bp,H) per-row partials of (dalpha,dbeta,da,db); finish with
+ * sparch_colsum_clamped().                                                           */
+int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
+                    const float* g_rate, const float* u_save, const float* w_save,
+                    const float* alpha, const float* beta, const float* a, const float* b,
+                    const float* u0, const float* w0, const float* s0, float theta,
+                    float p_drop, uint64_t seed, float* dWx, float* dparam_ws, void* stream);
+
+/* Recurrent kinds (RLIF, RadLIF).  V (H,H) = V.weight; the diagonal is masked inside
+ * (snns.py:566/712).  The recurrent product s_{t-1}*V runs on MFMA with the V slice of
+ * each workgroup resident in registers; workgroups of one 32-row batch tile exchange
+ * spikes through `chan` (tagged 8-byte granules, agent-scope write-through).
+ *   vpack   prepacked V from sparch_vpack (forward: transpose=0, backward: transpose=1)
+ *   rec0    (Bp,H) = s0 * Vmasked, the t=0 recurrent drive (s0 is not binary)
+ *   chan    sparch_rec_chan_bytes(Bp,T,H) bytes, zeroed by the call itself
+ *   status  1 uint32, set non-zero if an in-kernel wait gave up (SPARCH_ETIMEOUT)
+ *   steps_per_launch: T => one persistent launch per batch-tile group; 1 => one launch
+ *           per time step (no inter-workgroup waiting at all; the safe fallback).     */
+size_t sparch_vpack_bytes(int H);
+int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked,
+                 void* stream);
+size_t sparch_rec_chan_bytes(int Bp, int T, int H);
+int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
+                        const float* scale, const float* shift, const float* alpha,
+                        const float* beta, const float* a, const float* b,
+                        const float* vpack, const float* rec0, const float* u0,
+                        const float* w0, const float* s0, float theta, float p_drop,
+                        uint64_t seed, float* s_out, float* u_save, float* w_save,
+                        uint32_t* spike_count, void* chan, size_t chan_bytes,
+                        uint32_t* status, int steps_per_launch, void* stream);
+/* Backward: dWx doubles as the hand-off buffer (each step's 32x32 tile is published
+ * write-through and flagged in `chan`).  s_prev (Bp,T,H) receives s_{t-1} (s0 at t=0)
+ * for the dV = s_prev^T * dWx GEMM.                                                   */
+int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
+                        const float* g_rate, const float* u_save, const float* w_save,
+                        const float* alpha, const float* beta, const float* a,
+                        const float* b, const float* vpack_t, const float* u0,
+                        const float* w0, const float* s0, float theta, float p_drop,
+                        uint64_t seed, float* dWx, float* s_prev, float* dparam_ws,
+                        void* chan, size_t chan_bytes, uint32_t* status,
+                        int steps_per_launch, void* stream);
+
+/* Finish per-row partials: out[j][h] = sum_r ws[j][r][h], zeroed where the raw parameter
+ * lies outside [lo_j, hi_j] (torch.clamp's gradient gate).  n_params <= 4; raw[j]/lim may
+ * be NULL for "no clamp".                                                             */
+int sparch_colsum_clamped(int n_params, int rows, int H, const float* ws,
+                          const float* const* raw, const float* lim_lo_hi, float* const* out,
+                          void* stream);
+
+/* Elementwise helpers of the layer backward: out = x[0:B] + x[B:2B] (bidirectional
+ * halves of dWx share their projection rows), M*H elements.                           */
+int sparch_add_halves(size_t n, const float* x, float* out, void* stream);
+/* Column sums out[h] = sum_m x[m][h] (bias gradient), fixed order.                    */
+int sparch_colsum(int M, int H, const float* x, float* out, void* ws, size_t ws_bytes,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * G5  readout cell  (replaces _readout_cell, snns.py:808-825, and its autograd replay):
+ *     u_t = alpha*u + (1-alpha)*(Wx_t*scale+shift);  out += softmax(u_t).
+ *     One wave per batch row, classes on lanes (C <= 64).
+ * ---------------------------------------------------------------------------------- */
+int sparch_readout_fwd(int B, int T, int C, const float* Wx, const float* scale,
+                       const float* shift, const float* alpha, const float* u0, float* out,
+                       float* u_save, void* stream);
+int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* Wx,
+                       const float* scale, const float* shift, const float* u_save,
+                       const float* alpha, const float* u0, float* dWx, float* dalpha_ws,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * G9  mel filterbank front-end  (replaces torchaudio.compliance.kaldi.fbank(x,
+ *     num_mel_bins=40) at nonspiking_datasets.py:96,194; third-party, parity unpinned).
+ *     wave (n_clips, n_samples) fp32 in [-1,1], 16 kHz -> out (n_clips, frames, n_mels),
+ *     frames = 1 + (n_samples-400)/160.                                              */
+int sparch_fbank_frames(int n_samples);
+int sparch_fbank_fwd(int n_clips, int n_samples, int n_mels, const float* wave, float* out,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARCH_HIP_H */

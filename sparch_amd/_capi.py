@@ -1,0 +1,96 @@
+"""
+ctypes binding of libsparch_hip.so (include/sparch_hip.h).
+
+This is the only place the Python host touches native code.  Signatures carry
+plain pointers and sizes (no torch types); tensors are passed as
+`tensor.data_ptr()` and the stream as `torch.cuda.current_stream().cuda_stream`.
+There is NO CPU fallback: if the library is missing or a call fails, we raise.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparch_hip.so")
+
+SPARCH_OK = 0
+KIND = {"LIF": 0, "adLIF": 1, "RLIF": 2, "RadLIF": 3}
+
+P = c_void_p  # device (or host-array) pointer
+
+# name -> (restype, argtypes); kept in the header's order.  tests/test_capi.py checks this
+# table against every `sparch_*` declaration in include/sparch_hip.h.
+PROTOTYPES = {
+    "sparch_abi_version": (c_int, []),
+    "sparch_strerror": (c_char_p, [c_int]),
+    "sparch_device_cus": (c_int, []),
+    "sparch_gemm_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
+    "sparch_gemm_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
+    "sparch_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sparch_gemm_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, P, c_size_t, P]),
+    "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
+                                   P, P, P, P, P]),
+    "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "sparch_bn_bwd_reduce": (c_int, [c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
+    "sparch_bn_bwd_apply": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "sparch_layernorm_fwd": (c_int, [c_int, c_int, P, P, P, c_float, P, P, P, P]),
+    "sparch_layernorm_bwd": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "sparch_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P,
+                                c_float, c_float, c_uint64, P, P, P, P, P]),
+    "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
+                                c_float, c_float, c_uint64, P, P, P]),
+    "sparch_vpack_bytes": (c_size_t, [c_int]),
+    "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
+    "sparch_rec_chan_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sparch_rec_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                    c_float, c_float, c_uint64, P, P, P, P, P, c_size_t, P, c_int, P]),
+    "sparch_rec_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                    c_float, c_float, c_uint64, P, P, P, P, c_size_t, P, c_int, P]),
+    "sparch_colsum_clamped": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
+    "sparch_add_halves": (c_int, [c_size_t, P, P, P]),
+    "sparch_colsum": (c_int, [c_int, c_int, P, P, P, c_size_t, P]),
+    "sparch_readout_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "sparch_readout_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+    "sparch_fbank_frames": (c_int, [c_int]),
+    "sparch_fbank_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
+}
+
+
+class SparchHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: sparch_amd has no CPU fallback. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C sparch_amd/csrc`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = library/header mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def strerror(code):
+    return lib.sparch_strerror(int(code)).decode()
+
+
+def check(code, what):
+    """Map a negative return code onto the reference's Python error convention."""
+    if code == SPARCH_OK:
+        return
+    msg = f"{what}: {strerror(code)} (code {code})"
+    if code in (-1, -2):
+        raise ValueError(msg)
+    raise SparchHipError(msg)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,23 @@
+// ABI bookkeeping entry points of libsparch_hip.so.
+#include "common.h"
+
+extern "C" int sparch_abi_version(void) { return 1; }
+
+extern "C" const char* sparch_strerror(int code) {
+    switch (code) {
+        case SPARCH_OK: return "ok";
+        case SPARCH_EINVAL: return "invalid argument (shape, null pointer or unsupported size)";
+        case SPARCH_EALIGN: return "pointer or leading dimension is not 16-byte aligned";
+        case SPARCH_EWORKSPACE: return "workspace too small";
+        case SPARCH_ELAUNCH: return "HIP kernel launch failed";
+        case SPARCH_ETIMEOUT: return "in-kernel wait for a neighbouring workgroup gave up";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int sparch_device_cus(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return cus;
+}

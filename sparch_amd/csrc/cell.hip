@@ -1,0 +1,417 @@
+// G3/G4 (non-recurrent kinds), G5, G6, G7: fused spiking-cell kernels with the time
+// loop inside the kernel.
+//
+// Forward replaces _lif_cell (snns.py:282-303) and _adlif_cell (419-445) together
+// with SpikeFunctionBoxcar.forward (26-29), the bidirectional flip/cat glue
+// (252-254, 272-275), nn.Dropout (278) and the firing-rate reduction (174).
+// Backward replaces the autograd replay of those loops through
+// SpikeFunctionBoxcar.backward (31-36); recurrences in SURVEY.md §8a.
+//
+// Mapping: one thread owns VEC (4 or 1) adjacent neurons of one virtual batch row and
+// walks T in registers; lanes run along H so every global access of a wave is one
+// contiguous segment (1 KiB at VEC=4).  Loads of the U next time steps are issued
+// before the dependent arithmetic of the current ones (the inputs do not depend on the
+// recurrence), which is what hides HBM latency at one or two waves per SIMD.
+// Arithmetic keeps the reference's operation order with -ffp-contract=off, so given
+// identical inputs the spikes are bit-identical to the eager CPU path.
+// HBM-bound: 12H (LIF) / 16H (adLIF) bytes per sample-step forward, the same backward.
+#include "common.h"
+
+namespace {
+
+constexpr int U = 4;  // time steps of loads in flight per thread
+
+struct CellArgs {
+    int B, dirs, T, H;
+    const float* Wx; const float* scale; const float* shift;
+    const float* alpha; const float* beta; const float* a; const float* b;
+    const float* u0; const float* w0; const float* s0;
+    float theta, p_drop, inv_keep; uint64_t seed;
+    float* s_out; float* u_save; float* w_save; uint32_t* spike_count;
+    // backward
+    const float* g_out; const float* g_rate; float g_rate_scale;
+    float* dWx; float* dparam_ws;
+};
+
+template <int VEC>
+__device__ __forceinline__ void ldv(float (&d)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+        d[0] = p[0];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 4) {
+        f32x4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+        *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+        p[0] = d[0];
+    }
+}
+
+template <bool ADAPT, int VEC>
+__global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
+    const int HQ = c.H / VEC;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Bp = c.B * c.dirs;
+    if (idx >= (long long)Bp * HQ) return;
+    const int bp = (int)(idx / HQ), h = (int)(idx % HQ) * VEC;
+    const int d = bp / c.B, b = bp - d * c.B;
+    const int T = c.T, H = c.H, HO = c.H * c.dirs;
+
+    float al[VEC], oma[VEC], be[VEC], pa[VEC], pb[VEC], sc[VEC], sh[VEC];
+    float u[VEC], w[VEC], s[VEC];
+    uint32_t cnt[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        al[e] = clampf(c.alpha[h + e], SP_ALPHA_LO, SP_ALPHA_HI);
+        oma[e] = 1.0f - al[e];
+        if (ADAPT) {
+            be[e] = clampf(c.beta[h + e], SP_BETA_LO, SP_BETA_HI);
+            pa[e] = clampf(c.a[h + e], SP_A_LO, SP_A_HI);
+            pb[e] = clampf(c.b[h + e], SP_B_LO, SP_B_HI);
+        }
+        sc[e] = c.scale ? c.scale[h + e] : 1.0f;
+        sh[e] = c.scale ? c.shift[h + e] : 0.0f;
+        cnt[e] = 0;
+    }
+    ldv<VEC>(u, c.u0 + (size_t)bp * H + h);
+    ldv<VEC>(s, c.s0 + (size_t)bp * H + h);
+    if (ADAPT) ldv<VEC>(w, c.w0 + (size_t)bp * H + h);
+    const bool has_norm = c.scale != nullptr;
+    const bool drop = c.p_drop > 0.0f;
+
+    for (int t0 = 0; t0 < T; t0 += U) {
+        float x[U][VEC];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            if (t < T) {
+                const int tt = d ? (T - 1 - t) : t;
+                ldv<VEC>(x[j], c.Wx + ((size_t)b * T + tt) * H + h);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            if (t >= T) break;
+            const int tt = d ? (T - 1 - t) : t;
+            float so[VEC];
+            const size_t o = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xn = x[j][e];
+                if (has_norm) xn = xn * sc[e] + sh[e];
+                float drive = xn;
+                if (ADAPT) {
+                    w[e] = (be[e] * w[e] + pa[e] * u[e]) + pb[e] * s[e];  // snns.py:438
+                    drive = xn - w[e];
+                }
+                u[e] = al[e] * (u[e] - s[e]) + oma[e] * drive;           // snns.py:297 / 439
+                s[e] = (u[e] - c.theta) > 0.0f ? 1.0f : 0.0f;            // snns.py:29
+                const float k = drop ? keep_scale(c.seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+                so[e] = s[e] * k;
+                cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
+            }
+            stv<VEC>(c.s_out + o, so);
+            if (c.u_save) stv<VEC>(c.u_save + ((size_t)bp * T + t) * H + h, u);
+            if (ADAPT && c.w_save) stv<VEC>(c.w_save + ((size_t)bp * T + t) * H + h, w);
+        }
+    }
+    if (c.spike_count) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (cnt[e]) atomicAdd(c.spike_count + (size_t)d * H + h + e, cnt[e]);
+    }
+}
+
+template <bool ADAPT, int VEC>
+__global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
+    const int HQ = c.H / VEC;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Bp = c.B * c.dirs;
+    if (idx >= (long long)Bp * HQ) return;
+    const int bp = (int)(idx / HQ), h = (int)(idx % HQ) * VEC;
+    const int d = bp / c.B, b = bp - d * c.B;
+    const int T = c.T, H = c.H, HO = c.H * c.dirs;
+
+    float al[VEC], oma[VEC], be[VEC], pa[VEC], pb[VEC], gr[VEC];
+    float du_n[VEC], dw_n[VEC], u_t[VEC];
+    float acc_al[VEC], acc_be[VEC], acc_a[VEC], acc_b[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        al[e] = clampf(c.alpha[h + e], SP_ALPHA_LO, SP_ALPHA_HI);
+        oma[e] = 1.0f - al[e];
+        if (ADAPT) {
+            be[e] = clampf(c.beta[h + e], SP_BETA_LO, SP_BETA_HI);
+            pa[e] = clampf(c.a[h + e], SP_A_LO, SP_A_HI);
+            pb[e] = clampf(c.b[h + e], SP_B_LO, SP_B_HI);
+        }
+        gr[e] = c.g_rate ? c.g_rate[(size_t)d * H + h + e] * c.g_rate_scale : 0.0f;
+        du_n[e] = dw_n[e] = 0.f;
+        acc_al[e] = acc_be[e] = acc_a[e] = acc_b[e] = 0.f;
+    }
+    ldv<VEC>(u_t, c.u_save + ((size_t)bp * T + (T - 1)) * H + h);
+    const bool drop = c.p_drop > 0.0f;
+
+    for (int t0 = T - 1; t0 >= 0; t0 -= U) {
+        float g[U][VEC], up[U][VEC], wp[U][VEC];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 - j;
+            if (t >= 0) {
+                const int tt = d ? (T - 1 - t) : t;
+                ldv<VEC>(g[j], c.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + h);
+                if (t > 0) {
+                    ldv<VEC>(up[j], c.u_save + ((size_t)bp * T + (t - 1)) * H + h);
+                    if (ADAPT) ldv<VEC>(wp[j], c.w_save + ((size_t)bp * T + (t - 1)) * H + h);
+                } else {
+                    ldv<VEC>(up[j], c.u0 + (size_t)bp * H + h);
+                    if (ADAPT) ldv<VEC>(wp[j], c.w0 + (size_t)bp * H + h);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 - j;
+            if (t < 0) break;
+            const int tt = d ? (T - 1 - t) : t;
+            const size_t o = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
+            float sp[VEC], dwx[VEC];
+            if (t > 0) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sp[e] = (up[j][e] - c.theta) > 0.0f ? 1.0f : 0.0f;
+            } else {
+                ldv<VEC>(sp, c.s0 + (size_t)bp * H + h);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float k = drop ? keep_scale(c.seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+                const float gs = (g[j][e] + gr[e]) * k;
+                float ds = gs - al[e] * du_n[e];
+                if (ADAPT) ds = ds + pb[e] * dw_n[e];
+                const float xs = u_t[e] - c.theta;
+                const float box = (xs > -0.5f && xs <= 0.5f) ? 1.0f : 0.0f;  // snns.py:34-35
+                float du = ds * box + al[e] * du_n[e];
+                if (ADAPT) du = du + pa[e] * dw_n[e];
+                dwx[e] = oma[e] * du;
+                const float q = up[j][e] - sp[e];
+                acc_al[e] += du * (q - u_t[e]);  // d u_t / d alpha = (q - u_t)/(1-alpha); scaled at the end
+                if (ADAPT) {
+                    const float dw = be[e] * dw_n[e] - dwx[e];
+                    acc_be[e] += dw * wp[j][e];
+                    acc_a[e] += dw * up[j][e];
+                    acc_b[e] += dw * sp[e];
+                    dw_n[e] = dw;
+                }
+                du_n[e] = du;
+                u_t[e] = up[j][e];
+            }
+            stv<VEC>(c.dWx + ((size_t)bp * T + tt) * H + h, dwx);
+        }
+    }
+    const size_t plane = (size_t)Bp * H;
+    float* ws = c.dparam_ws + (size_t)bp * H + h;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc_al[e] = acc_al[e] / oma[e];
+    stv<VEC>(ws, acc_al);
+    if (ADAPT) {
+        stv<VEC>(ws + plane, acc_be);
+        stv<VEC>(ws + 2 * plane, acc_a);
+        stv<VEC>(ws + 3 * plane, acc_b);
+    }
+}
+
+// ------------------------------------------------------------------ readout cell
+// One wave per batch row, classes on lanes.  out += softmax(u_t) each step
+// (snns.py:819-823); wave-level max / sum via cross-lane shuffles.
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int RU = 8;
+
+__global__ __launch_bounds__(256) void readout_fwd_kernel(int B, int T, int C, const float* __restrict__ Wx,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ alpha,
+                                                          const float* __restrict__ u0, float* __restrict__ out,
+                                                          float* __restrict__ u_save) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const bool act = lane < C;
+    const int cc = act ? lane : 0;
+    const float al = clampf(alpha[cc], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
+    const float sc = scale ? scale[cc] : 1.0f, sh = scale ? shift[cc] : 0.0f;
+    float u = u0[(size_t)b * C + cc], acc = 0.f;
+    const float* xr = Wx + (size_t)b * T * C + cc;
+    for (int t0 = 0; t0 < T; t0 += RU) {
+        float x[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) x[j] = (t0 + j < T) ? xr[(size_t)(t0 + j) * C] : 0.f;
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            if (t0 + j >= T) break;
+            float xn = x[j];
+            if (scale) xn = xn * sc + sh;
+            u = al * u + oma * xn;                                   // snns.py:822
+            const float m = wmax(act ? u : -INFINITY);
+            const float ex = act ? expf(u - m) : 0.f;
+            const float den = wsum(ex);
+            acc = acc + ex / den;                                    // snns.py:823
+            if (act && u_save) u_save[((size_t)b * T + t0 + j) * C + cc] = u;
+        }
+    }
+    if (act) out[(size_t)b * C + cc] = acc;
+}
+
+__global__ __launch_bounds__(256) void readout_bwd_kernel(int B, int T, int C, const float* __restrict__ g_out,
+                                                          const float* __restrict__ u_save,
+                                                          const float* __restrict__ alpha,
+                                                          const float* __restrict__ u0, float* __restrict__ dWx,
+                                                          float* __restrict__ dalpha_ws) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const bool act = lane < C;
+    const int cc = act ? lane : 0;
+    const float al = clampf(alpha[cc], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
+    const float g = act ? g_out[(size_t)b * C + cc] : 0.f;
+    const float* ur = u_save + (size_t)b * T * C + cc;
+    float du = 0.f, acc = 0.f;
+    float u_t = ur[(size_t)(T - 1) * C];
+    for (int t0 = T - 1; t0 >= 0; t0 -= RU) {
+        float up[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            const int t = t0 - j;
+            up[j] = (t > 0) ? ur[(size_t)(t - 1) * C] : u0[(size_t)b * C + cc];
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            const int t = t0 - j;
+            if (t < 0) break;
+            const float m = wmax(act ? u_t : -INFINITY);
+            const float ex = act ? expf(u_t - m) : 0.f;
+            const float p = ex / wsum(ex);
+            const float dot = wsum(p * g);
+            du = al * du + p * (g - dot);
+            if (act) dWx[((size_t)b * T + t) * C + cc] = oma * du;
+            acc += du * (up[j] - u_t);
+            u_t = up[j];
+        }
+    }
+    if (act) dalpha_ws[(size_t)b * C + cc] = acc / oma;
+}
+
+template <bool ADAPT>
+int launch_cell(bool bwd, CellArgs& c, hipStream_t st) {
+    const long long work = (long long)c.B * c.dirs * c.H;
+    const bool vec_ok = (c.H % 4 == 0);
+    // VEC=4 only when it still leaves >= 8 waves per CU; small problems favour more threads
+    const bool vec4 = vec_ok && work >= (long long)256 * 8 * 64 * 4;
+    const long long threads = vec4 ? work / 4 : work;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (!bwd) {
+        if (vec4) hipLaunchKernelGGL((cell_fwd_kernel<ADAPT, 4>), dim3(blocks), dim3(256), 0, st, c);
+        else      hipLaunchKernelGGL((cell_fwd_kernel<ADAPT, 1>), dim3(blocks), dim3(256), 0, st, c);
+    } else {
+        if (vec4) hipLaunchKernelGGL((cell_bwd_kernel<ADAPT, 4>), dim3(blocks), dim3(256), 0, st, c);
+        else      hipLaunchKernelGGL((cell_bwd_kernel<ADAPT, 1>), dim3(blocks), dim3(256), 0, st, c);
+    }
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+bool ptrs_aligned(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
+                               const float* scale, const float* shift, const float* alpha,
+                               const float* beta, const float* a, const float* b, const float* u0,
+                               const float* w0, const float* s0, float theta, float p_drop,
+                               uint64_t seed, float* s_out, float* u_save, float* w_save,
+                               uint32_t* spike_count, void* stream) {
+    if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
+    const bool adapt = kind == SPARCH_KIND_ADLIF;
+    if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !Wx || !alpha || !u0 || !s0 || !s_out)
+        return SPARCH_EINVAL;
+    if (adapt && (!beta || !a || !b || !w0)) return SPARCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!ptrs_aligned({Wx, u0, w0, s0, s_out, u_save, w_save})) return SPARCH_EALIGN;
+    CellArgs c{};
+    c.B = B; c.dirs = dirs; c.T = T; c.H = H;
+    c.Wx = Wx; c.scale = scale; c.shift = shift;
+    c.alpha = alpha; c.beta = beta; c.a = a; c.b = b;
+    c.u0 = u0; c.w0 = w0; c.s0 = s0;
+    c.theta = theta; c.p_drop = p_drop; c.inv_keep = 1.0f / (1.0f - p_drop); c.seed = seed;
+    c.s_out = s_out; c.u_save = u_save; c.w_save = w_save; c.spike_count = spike_count;
+    return adapt ? launch_cell<true>(false, c, (hipStream_t)stream)
+                 : launch_cell<false>(false, c, (hipStream_t)stream);
+}
+
+extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
+                               const float* g_rate, const float* u_save, const float* w_save,
+                               const float* alpha, const float* beta, const float* a, const float* b,
+                               const float* u0, const float* w0, const float* s0, float theta,
+                               float p_drop, uint64_t seed, float* dWx, float* dparam_ws, void* stream) {
+    if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
+    const bool adapt = kind == SPARCH_KIND_ADLIF;
+    if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !g_out || !u_save || !alpha || !u0 ||
+        !s0 || !dWx || !dparam_ws)
+        return SPARCH_EINVAL;
+    if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!ptrs_aligned({g_out, u_save, w_save, u0, w0, s0, dWx, dparam_ws})) return SPARCH_EALIGN;
+    CellArgs c{};
+    c.B = B; c.dirs = dirs; c.T = T; c.H = H;
+    c.alpha = alpha; c.beta = beta; c.a = a; c.b = b;
+    c.u0 = u0; c.w0 = w0; c.s0 = s0;
+    c.theta = theta; c.p_drop = p_drop; c.inv_keep = 1.0f / (1.0f - p_drop); c.seed = seed;
+    c.u_save = const_cast<float*>(u_save); c.w_save = const_cast<float*>(w_save);
+    c.g_out = g_out; c.g_rate = g_rate; c.g_rate_scale = 1.0f / ((float)B * (float)T);
+    c.dWx = dWx; c.dparam_ws = dparam_ws;
+    return adapt ? launch_cell<true>(true, c, (hipStream_t)stream)
+                 : launch_cell<false>(true, c, (hipStream_t)stream);
+}
+
+extern "C" int sparch_readout_fwd(int B, int T, int C, const float* Wx, const float* scale,
+                                  const float* shift, const float* alpha, const float* u0, float* out,
+                                  float* u_save, void* stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !Wx || !alpha || !u0 || !out) return SPARCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(readout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, B, T, C, Wx,
+                       scale, shift, alpha, u0, out, u_save);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* Wx,
+                                  const float* scale, const float* shift, const float* u_save,
+                                  const float* alpha, const float* u0, float* dWx, float* dalpha_ws,
+                                  void* stream) {
+    (void)Wx; (void)scale; (void)shift;  // dalpha uses u_{t-1}-x_t = (u_{t-1}-u_t)/(1-alpha): no re-read of Wx
+    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
+        return SPARCH_EINVAL;
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, B, T, C, g_out,
+                       u_save, alpha, u0, dWx, dalpha_ws);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}

@@ -1,0 +1,44 @@
+// Shared device/host helpers for libsparch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sparch_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SPARCH_CHECK_LAUNCH()                          \
+    do {                                               \
+        if (hipGetLastError() != hipSuccess) return SPARCH_ELAUNCH; \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Clamp ranges of the neuron parameters (snns.py:229, 356-359, 631-634), as the
+// float32 values torch.clamp compares against (Python doubles rounded to f32).
+#define SP_ALPHA_LO 0x1.a330aep-1f /* float32(exp(-1/5))   */
+#define SP_ALPHA_HI 0x1.ebec98p-1f /* float32(exp(-1/25))  */
+#define SP_BETA_LO 0x1.ef36f2p-1f  /* float32(exp(-1/30))  */
+#define SP_BETA_HI 0x1.fbc046p-1f  /* float32(exp(-1/120)) */
+#define SP_A_LO (-1.0f)
+#define SP_A_HI 1.0f
+#define SP_B_LO 0.0f
+#define SP_B_HI 2.0f
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    return fminf(fmaxf(x, lo), hi);
+}
+
+// Dropout decision for output element `idx` of a layer: a counter-based hash
+// (splitmix64 finaliser) of (seed, idx); keep iff uniform >= p.  Forward and
+// backward regenerate the same mask from (seed, idx), nothing is stored.
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24-bit uniform [0,1)
+    return u >= p ? inv_keep : 0.0f;
+}

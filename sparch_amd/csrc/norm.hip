@@ -1,0 +1,372 @@
+// G2: normalisation on the (M = B*T, H) view of the projection, and the small
+// fixed-order column reductions used by the layer backward.
+//
+// Replaces nn.BatchNorm1d(H, momentum=0.05) / nn.LayerNorm(H) applied at
+// snns.py:264-266 (layers built at 240 / 243).  BatchNorm never materialises the
+// normalised tensor: statistics come from the projection GEMM's epilogue partials
+// and are folded into a per-column (scale, shift) that the cell kernels apply on
+// load:  y = x*scale + shift,  scale = gamma*invstd,  shift = beta - mean*scale.
+// All column reductions are two-stage with fixed summation order (no float
+// atomics) so results are bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 256;  // rows per partial block in column reductions
+
+// ---------------------------------------------------------------- BatchNorm forward
+__global__ void bn_finalize_kernel(int H, int M, int n_tiles, int dup, const float* __restrict__ ws,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                   float eps, int training, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float mean, var;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int t = 0; t < n_tiles; ++t) {
+            s += (double)ws[(size_t)t * H + h];
+            ss += (double)ws[(size_t)(n_tiles + t) * H + h];
+        }
+        const double mu = s / (double)M;
+        double v = ss / (double)M - mu * mu;
+        if (v < 0.0) v = 0.0;
+        mean = (float)mu;
+        var = (float)v;
+        const double n = (double)M * (double)dup;
+        const float unbiased = (float)(v * (n / (n - 1.0)));
+        rmean[h] = momentum * mean + (1.0f - momentum) * rmean[h];
+        rvar[h] = momentum * unbiased + (1.0f - momentum) * rvar[h];
+    } else {
+        mean = rmean[h];
+        var = rvar[h];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[h] * invstd;
+    scale[h] = sc;
+    shift[h] = beta[h] - mean * sc;
+    if (save_mean) save_mean[h] = mean;
+    if (save_invstd) save_invstd[h] = invstd;
+}
+
+// ---------------------------------------------------------------- column reductions
+// Partial sums over RB rows for 256 columns per block (4 waves x 64 lanes x float4... here
+// one column per lane-slot of a float4).  MODE 0: sum x.  MODE 1: (sum dy, sum dy*xhat) with
+// per-column mean/invstd (BatchNorm).  MODE 2: same with per-row mu/rstd (LayerNorm).
+template <int MODE>
+__global__ __launch_bounds__(256) void colpartial_kernel(int M, int H, const float* __restrict__ dy,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ p0,
+                                                         const float* __restrict__ p1,
+                                                         float* __restrict__ ws, int n_rb) {
+    __shared__ float red[2][4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int rb = blockIdx.y;
+    const int r_begin = rb * RB;
+    const int r_end = min(M, r_begin + RB);
+    const bool vec = (H % 4 == 0);
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    float cm[4] = {0, 0, 0, 0}, ci[4] = {1, 1, 1, 1};
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < H) { cm[e] = p0[c + e]; ci[e] = p1[c + e]; }
+    }
+    for (int r = r_begin + wave; r < r_end; r += 4) {
+        float d[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+        const size_t off = (size_t)r * H + c;
+        if (vec && c + 3 < H) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + off);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (MODE != 0) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(x + off);
+                xv[0] = w.x; xv[1] = w.y; xv[2] = w.z; xv[3] = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < H) { d[e] = dy[off + e]; if (MODE != 0) xv[e] = x[off + e]; }
+        }
+        float rm = 0.f, ri = 1.f;
+        if (MODE == 2) { rm = p0[r]; ri = p1[r]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0[e] += d[e];
+            if (MODE == 1) a1[e] += d[e] * ((xv[e] - cm[e]) * ci[e]);
+            if (MODE == 2) a1[e] += d[e] * ((xv[e] - rm) * ri);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][wave][lane * 4 + e] = a0[e]; red[1][wave][lane * 4 + e] = a1[e]; }
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < H) {
+        const int t = threadIdx.x;
+        ws[(size_t)rb * H + cc] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+        if (MODE != 0) ws[(size_t)(n_rb + rb) * H + cc] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    }
+}
+
+__global__ void colfinish_kernel(int H, int n_rb, int n_out, const float* __restrict__ ws,
+                                 float* __restrict__ out0, float* __restrict__ out1) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < n_rb; ++r) {
+        s0 += (double)ws[(size_t)r * H + h];
+        if (n_out > 1) s1 += (double)ws[(size_t)(n_rb + r) * H + h];
+    }
+    out0[h] = (float)s0;
+    if (n_out > 1) out1[h] = (float)s1;
+}
+
+// dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M)
+__global__ void bn_bwd_apply_kernel(size_t n4, int H, float invM, const float* __restrict__ dy,
+                                    const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % (size_t)H);
+    const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float is = invstd[c + e];
+        const float xh = (xv[e] - mean[c + e]) * is;
+        o[e] = gamma[c + e] * is * (d[e] - dbeta[c + e] * invM - xh * (dgamma[c + e] * invM));
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+}
+
+__global__ void bn_bwd_apply_scalar_kernel(size_t n, int H, float invM, const float* __restrict__ dy,
+                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                           float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % (size_t)H);
+    const float is = invstd[c];
+    const float xh = (x[i] - mean[c]) * is;
+    dx[i] = gamma[c] * is * (dy[i] - dbeta[c] * invM - xh * (dgamma[c] * invM));
+}
+
+// ---------------------------------------------------------------- LayerNorm (one wave per row)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int H, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ y, float* __restrict__ mu,
+                                                            float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)H;
+    const float rs = 1.0f / sqrtf(var + eps);
+    float* yr = y + (size_t)row * H;
+    for (int c = lane; c < H; c += 64) yr[c] = (xr[c] - mean) * rs * gamma[c] + beta[c];
+    if (lane == 0) { mu[row] = mean; rstd[row] = rs; }
+}
+
+// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = gamma*dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int H, const float* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ mu,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float m = mu[row], rs = rstd[row];
+    const float* xr = x + (size_t)row * H;
+    const float* dr = dy + (size_t)row * H;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float g = gamma[c] * dr[c];
+        s1 += g;
+        s2 += g * ((xr[c] - m) * rs);
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    float* o = dx + (size_t)row * H;
+    for (int c = lane; c < H; c += 64) {
+        const float xh = (xr[c] - m) * rs;
+        o[c] = rs * (gamma[c] * dr[c] - s1 - xh * s2);
+    }
+}
+
+// ---------------------------------------------------------------- misc elementwise
+__global__ void add_halves_kernel(size_t n, const float* __restrict__ x, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] + x[n + i];
+}
+
+// out[j][h] = gate_j(h) * sum_r ws[j][r][h]
+struct ClampArgs {
+    const float* raw[4];
+    float* out[4];
+    float lo[4], hi[4];
+    int gated[4];
+};
+__global__ void colsum_clamped_kernel(int n_params, int rows, int H, const float* __restrict__ ws,
+                                      ClampArgs a) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (h >= H || j >= n_params) return;
+    const float* p = ws + (size_t)j * rows * H + h;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)p[(size_t)r * H];
+    float v = (float)s;
+    if (a.gated[j]) {
+        const float x = a.raw[j][h];
+        if (!(x >= a.lo[j] && x <= a.hi[j])) v = 0.f;
+    }
+    a.out[j][h] = v;
+}
+
+}  // namespace
+
+extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const float* colstat_ws,
+                                  const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, int training,
+                                  float* scale, float* shift, float* save_mean, float* save_invstd,
+                                  void* stream) {
+    if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
+    if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, H, M,
+                       n_tiles, dup, colstat_ws, gamma, beta, running_mean, running_var, momentum, eps,
+                       training, scale, shift, save_mean, save_invstd);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" size_t sparch_bn_bwd_workspace_bytes(int M, int H) {
+    if (M <= 0 || H <= 0) return 0;
+    return (size_t)2 * cdiv(M, RB) * H * sizeof(float);
+}
+
+extern "C" int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* x, const float* mean,
+                                    const float* invstd, float* dgamma, float* dbeta, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    if (M <= 0 || H <= 0 || !dy || !x || !mean || !invstd || !dgamma || !dbeta) return SPARCH_EINVAL;
+    if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
+    if (!aligned16(dy) || !aligned16(x)) return SPARCH_EALIGN;
+    const int n_rb = cdiv(M, RB);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colpartial_kernel<1>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mean,
+                       invstd, (float*)ws, n_rb);
+    SPARCH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+                       dbeta, dgamma);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x, const float* mean,
+                                   const float* invstd, const float* gamma, const float* dgamma,
+                                   const float* dbeta, float* dx, void* stream) {
+    if (M <= 0 || H <= 0 || !dy || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx)
+        return SPARCH_EINVAL;
+    const size_t n = (size_t)M * H;
+    hipStream_t st = (hipStream_t)stream;
+    if (H % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(dx)) {
+        const size_t n4 = n / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, H,
+                           1.0f / (float)M, dy, x, mean, invstd, gamma, dgamma, dbeta, dx);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
+                           H, 1.0f / (float)M, dy, x, mean, invstd, gamma, dgamma, dbeta, dx);
+    }
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_layernorm_fwd(int M, int H, const float* x, const float* gamma, const float* beta,
+                                    float eps, float* y, float* mu, float* rstd, void* stream) {
+    if (M <= 0 || H <= 0 || !x || !gamma || !beta || !y || !mu || !rstd) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, H, x,
+                       gamma, beta, eps, y, mu, rstd);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const float* mu,
+                                    const float* rstd, const float* gamma, float* dx, float* dgamma,
+                                    float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || H <= 0 || !dy || !x || !mu || !rstd || !gamma || !dx || !dgamma || !dbeta) return SPARCH_EINVAL;
+    if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
+    if (!aligned16(dy) || !aligned16(x)) return SPARCH_EALIGN;
+    const int n_rb = cdiv(M, RB);
+    hipStream_t st = (hipStream_t)stream;
+    // column sums first (dx may alias dy)
+    hipLaunchKernelGGL(colpartial_kernel<2>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mu, rstd,
+                       (float*)ws, n_rb);
+    SPARCH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+                       dbeta, dgamma);
+    SPARCH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, M, H, dy, x, mu, rstd, gamma,
+                       dx);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_colsum(int M, int H, const float* x, float* out, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (M <= 0 || H <= 0 || !x || !out) return SPARCH_EINVAL;
+    if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
+    if (!aligned16(x)) return SPARCH_EALIGN;
+    const int n_rb = cdiv(M, RB);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colpartial_kernel<0>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, x, x,
+                       (const float*)nullptr, (const float*)nullptr, (float*)ws, n_rb);
+    SPARCH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 1, (const float*)ws, out,
+                       (float*)nullptr);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_add_halves(size_t n, const float* x, float* out, void* stream) {
+    if (n == 0 || !x || !out) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(add_halves_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       n, x, out);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_colsum_clamped(int n_params, int rows, int H, const float* ws,
+                                     const float* const* raw, const float* lim_lo_hi, float* const* out,
+                                     void* stream) {
+    if (n_params < 1 || n_params > 4 || rows <= 0 || H <= 0 || !ws || !out) return SPARCH_EINVAL;
+    ClampArgs a{};
+    for (int j = 0; j < n_params; ++j) {
+        if (!out[j]) return SPARCH_EINVAL;
+        a.out[j] = out[j];
+        a.raw[j] = raw ? raw[j] : nullptr;
+        a.gated[j] = (raw && raw[j] && lim_lo_hi) ? 1 : 0;
+        if (a.gated[j]) { a.lo[j] = lim_lo_hi[2 * j]; a.hi[j] = lim_lo_hi[2 * j + 1]; }
+    }
+    hipLaunchKernelGGL(colsum_clamped_kernel, dim3(cdiv(H, 256), n_params), dim3(256), 0, (hipStream_t)stream,
+                       n_params, rows, H, ws, a);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}

