@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""
+bench.py — BASELINE.json metric: train-step timesteps*samples/sec, RadLIF 3x1024 on synthetic
+SSC-shaped input (B=256 per GPU, T=250, C=700), fp32, at 1/2/4/8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the training hot path over one resident synthetic batch:
+zero_grad -> SNN.forward -> cross-entropy on the softmax-sum -> backward (-> per-layer RCCL
+gradient all-reduce, overlapped) -> Adam.step   (reference: exp.py:359-377).
+Inputs are in HBM before the timed region.  N>1 is weak scaling: every rank runs the full
+B=256 batch (data parallel, no data-path collective; only the gradient all-reduce).
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  "roofline":     dominant kernel's achieved algorithmic rate vs the gfx950 peak (HIP events, live)
+  "cpu_baseline": the CPU oracle (a validated restatement of the reference's eager PyTorch path,
+                  oracle/snn_oracle.py) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured achievable)
+
+WORKLOAD = dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1)
+
+
+def algorithmic_work(name, B, T, H):
+    """(bound, amount per launch, unit) for a timed call — SURVEY.md §8(d) figures, stated in DESIGN.md."""
+    m = re.match(r"gemm_(nt|nn|tn)\[(\d+)x(\d+)x(\d+)\]", name)
+    if m:
+        M, N, K = int(m.group(2)), int(m.group(3)), int(m.group(4))
+        return "mfma", 2.0 * M * N * K, "flop"
+    if name.startswith("rec_cell_fwd") or name.startswith("rec_cell_bwd"):
+        # one (B x H) x (H x H) recurrent product per time step (s_{t-1} V  or  dWx_{t+1} V^T)
+        return "mfma", 2.0 * B * H * H * T, "flop"
+    if name.startswith("cell_fwd") or name.startswith("cell_bwd"):
+        per = 16 if "adLIF" in name else 12  # bytes per neuron-step: Wx + s + u (+ w) | g + u (+ w) + dWx
+        return "hbm", float(per) * B * T * H, "byte"
+    return None
+
+
+def cpu_baseline(rank):
+    """The oracle on the host cores, bounded sample of the same workload (same model, B=64 of 256)."""
+    from oracle import snn_oracle as orc
+
+    n_threads = os.cpu_count() or 1
+    torch.set_num_threads(n_threads)
+    Bs, T, C = 64, WORKLOAD["T"], WORKLOAD["C"]
+    sizes = WORKLOAD["layer_sizes"]
+    g = torch.Generator().manual_seed(1234)
+    H = sizes[0]
+    p = {}
+    fan = C
+    for i in range(2):
+        p[f"snn.{i}.W.weight"] = (torch.rand(H, fan, generator=g) * 2 - 1) / fan ** 0.5
+        p[f"snn.{i}.V.weight"] = torch.nn.init.orthogonal_(torch.empty(H, H), generator=g)
+        p[f"snn.{i}.alpha"] = torch.rand(H, generator=g) * 0.14 + 0.82
+        p[f"snn.{i}.beta"] = torch.rand(H, generator=g) * 0.024 + 0.967
+        p[f"snn.{i}.a"] = torch.rand(H, generator=g) * 2 - 1
+        p[f"snn.{i}.b"] = torch.rand(H, generator=g) * 2
+        p[f"snn.{i}.norm.weight"], p[f"snn.{i}.norm.bias"] = torch.ones(H), torch.zeros(H)
+        p[f"snn.{i}.norm.running_mean"], p[f"snn.{i}.norm.running_var"] = torch.zeros(H), torch.ones(H)
+        fan = H
+    Co = sizes[-1]
+    p["snn.2.W.weight"] = (torch.rand(Co, H, generator=g) * 2 - 1) / H ** 0.5
+    p["snn.2.alpha"] = torch.rand(Co, generator=g) * 0.14 + 0.82
+    p["snn.2.norm.weight"], p["snn.2.norm.bias"] = torch.ones(Co), torch.zeros(Co)
+    p["snn.2.norm.running_mean"], p["snn.2.norm.running_var"] = torch.zeros(Co), torch.ones(Co)
+    for k, v in p.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    x = (torch.rand(Bs, T, C, generator=g) < 0.05).float()
+    y = torch.randint(0, Co, (Bs,), generator=g)
+    torch.manual_seed(7)
+    init = orc.draw_init_states(Bs, sizes, "RadLIF")
+    t0 = time.perf_counter()
+    out, rates = orc.snn_forward(x, p, neuron_type="RadLIF", num_layers=3, init_states=init, training=True,
+                                 stats={})
+    loss = orc.train_step_loss(out, rates, y)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": Bs * T / dt, "unit": "timesteps*samples/s", "cores": n_threads, "kind": "port",
+            "sample": f"1 fwd+bwd of the same RadLIF [1024,1024,35] model at B={Bs} (of 256), T={T}, C={C}, "
+                      f"pdrop=0, eager torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import sparch_amd
+    from sparch_amd import dp
+    from sparch_amd import functional as Fn
+
+    rank, world, local = dp.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    w = WORKLOAD
+    B, T, C, H = w["B"], w["T"], w["C"], w["layer_sizes"][0]
+    torch.manual_seed(1234)
+    net = sparch_amd.SNN((B, None, C), w["layer_sizes"], neuron_type=w["neuron_type"], dropout=w["pdrop"],
+                         normalization="batchnorm").to(dev)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), 1e-2)  # exp.py:89
+    loss_fn = torch.nn.CrossEntropyLoss()           # exp.py:100
+    reducer = dp.GradAllReducer(net) if world > 1 else None
+    g = torch.Generator().manual_seed(4321 + rank)
+    x = (torch.rand(B, T, C, generator=g) < 0.05).float().to(dev)
+    y = torch.randint(0, w["layer_sizes"][-1], (B,), generator=g).to(dev)
+    torch.manual_seed(99 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, rates = net(x)
+        loss = loss_fn(out, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    Fn.check_status(dev)
+    Fn.timer.reset()
+    Fn.timer.enabled = True
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    Fn.timer.enabled = False
+    totals = Fn.timer.collect()
+    Fn.check_status(dev)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = world * B * T * args.steps / dt
+        # dominant kernel by total time inside the timed region
+        kern = {k: {"launches": c, "avg_ms": t / c} for k, (c, t) in totals.items()}
+        dom = max(totals.items(), key=lambda kv: kv[1][1])[0] if totals else None
+        roof = None
+        if dom is not None:
+            bound, amount, _ = algorithmic_work(dom, B, T, H)
+            avg_s = kern[dom]["avg_ms"] * 1e-3
+            if bound == "mfma":
+                ach = amount / avg_s / 1e12
+                roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                        "avg_ms": kern[dom]["avg_ms"]}
+            else:
+                ach = amount / avg_s / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": kern[dom]["avg_ms"]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(rank)
+        line = {
+            "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), RadLIF 3x1024 SSC shape",
+            "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RadLIF [1024,1024,35] batchnorm pdrop=0.1, B=256/GPU T=250 C=700 "
+                                   "Bernoulli(0.05) spikes (BASELINE.json configs[2])",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k: round(v["avg_ms"] * v["launches"] / args.steps, 4) for k, v in kern.items()},
+            "final_loss": final_loss,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,6 +219,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     C[(size_t)m * ldc + n] = s;
 }
 
+__global__ void zero_diag_kernel(float* __restrict__ C, int n, int ldc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) C[(size_t)i * ldc + i] = 0.f;
+}
+
 int choose_splits(int M, int N, int K) {
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     const int kt = cdiv(K, BK);
@@ -282,9 +287,14 @@ extern "C" int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, cons
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
-    if (splits == 1 && !zero_diag) {
+    if (splits == 1) {
         g.C = C; g.ldc = ldc; g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0;
-        return launch<true, true, EPI_NONE>(g, 1, st);
+        int rc = launch<true, true, EPI_NONE>(g, 1, st);
+        if (rc != SPARCH_OK || !zero_diag) return rc;
+        const int n = M < N ? M : N;
+        hipLaunchKernelGGL(zero_diag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, C, n, ldc);
+        SPARCH_CHECK_LAUNCH();
+        return SPARCH_OK;
     }
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;

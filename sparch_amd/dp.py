@@ -1,0 +1,116 @@
+"""
+Single-node data parallelism for the spiking training step: one process per GPU,
+gradient all-reduce (mean) over RCCL/xGMI.  NEW functionality — the reference is
+single-device only (exp.py:81 is its one device decision).
+
+Samples are independent through the whole time loop, so the batch shards across
+ranks with no data-path exchange; the only collective is the gradient all-reduce:
+15.6 MB fp32 at RadLIF 3x1024.  A layer's backward is ONE autograd node (its reverse
+time loop + GEMMs), so all of a layer's parameter gradients appear together.  We
+bucket per layer: a post-accumulate-grad hook counts a layer's parameters and, when
+the last one lands, flattens the bucket and launches an async all-reduce — which
+then runs on RCCL's stream underneath the next (earlier) layer's reverse time loop.
+`finish()` waits, averages and scatters the buckets back before `optimizer.step()`.
+
+BatchNorm statistics stay per-rank (standard DDP semantics).
+Works with any torch.distributed backend: "nccl" (= RCCL) on GPUs, "gloo" in CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, module, process_group=None, buckets=None):
+        """buckets: list of lists of parameters (default: one bucket per child of `module.snn`,
+        or a single bucket for arbitrary modules).  Buckets fire in whatever order backward
+        completes them (readout first, input layer last)."""
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if buckets is None:
+            if hasattr(module, "snn"):
+                buckets = [[p for p in layer.parameters() if p.requires_grad] for layer in module.snn]
+            else:
+                buckets = [[p for p in module.parameters() if p.requires_grad]]
+        self.buckets = [b for b in buckets if b]
+        self._pending = [0] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._handles = []
+        self.bytes_per_step = sum(p.numel() * 4 for b in self.buckets for p in b)
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.reset()
+
+    def reset(self):
+        for bi, b in enumerate(self.buckets):
+            self._pending[bi] = len(b)
+            self._flat[bi] = None
+            self._work[bi] = None
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.buckets[bi]]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self._flat[bi] = flat
+        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket, write the mean back into .grad, re-arm for the next step."""
+        if self.world > 1:
+            inv = 1.0 / self.world
+            for bi, bucket in enumerate(self.buckets):
+                if self._work[bi] is None:
+                    if self._pending[bi] != len(bucket) and self._pending[bi] != 0:
+                        raise RuntimeError("GradAllReducer: a bucket received only part of its gradients")
+                    if self._pending[bi] == len(bucket):
+                        continue  # layer took no part in this backward
+                self._work[bi].wait()
+                flat = self._flat[bi]
+                off = 0
+                for p in bucket:
+                    n = p.numel()
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad) * inv)
+                    off += n
+        self.reset()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def shard_batch(x, rank, world):
+    """Rows [rank*B/world, (rank+1)*B/world) of a global batch (SURVEY.md §8e partitioning)."""
+    B = x.shape[0]
+    if B % world != 0:
+        raise ValueError(f"global batch {B} is not divisible by world size {world}")
+    per = B // world
+    return x[rank * per:(rank + 1) * per]
+
+
+def init_from_env(backend=None):
+    """torch.distributed rendezvous from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank)."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local

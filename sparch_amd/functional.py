@@ -27,6 +27,44 @@ B_LIM = (0.0, 2.0)  # snns.py:359
 _status = {}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of named C-ABI calls on the current stream (bench.py uses it for
+    the roofline object).  Disabled by default: zero overhead on the training path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pending = []   # (name, start_event, end_event)
+        self.totals = {}    # name -> [count, total_ms]
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (name, a, b)
+
+    def stop(self, tok):
+        if tok is not None:
+            tok[2].record()
+            self.pending.append(tok)
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for name, a, b in self.pending:
+            c = self.totals.setdefault(name, [0, 0.0])
+            c[0] += 1
+            c[1] += a.elapsed_time(b)
+        self.pending = []
+        return self.totals
+
+    def reset(self):
+        self.pending, self.totals = [], {}
+
+
+timer = KernelTimer()
+
+
 def _require_device(t, what):
     if not t.is_cuda:
         raise RuntimeError(
@@ -74,8 +112,10 @@ def gemm_nt(A, B, bias=None, colstat=False):
     ws = None
     if colstat:
         ws = torch.empty(2 * ((M + 127) // 128) * N, dtype=torch.float32, device=A.device)
+    tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
     check(lib.sparch_gemm_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
                              ptr(ws), _stream()), "sparch_gemm_nt")
+    timer.stop(tok)
     return C, ws
 
 
@@ -84,8 +124,10 @@ def gemm_nn(A, B):
     M, K = A.shape
     N = B.shape[1]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    tok = timer.start(f"gemm_nn[{M}x{N}x{K}]")
     check(lib.sparch_gemm_nn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()),
           "sparch_gemm_nn")
+    timer.stop(tok)
     return C
 
 
@@ -96,8 +138,10 @@ def gemm_tn(A, B, zero_diag=False):
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
     nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+    tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
     check(lib.sparch_gemm_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, int(zero_diag),
                              ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
+    timer.stop(tok)
     return C
 
 
@@ -199,10 +243,12 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
     w_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev) if adaptive else None
     count = torch.zeros(H * dirs, dtype=torch.int32, device=dev)
     if not recurrent:
+        tok = timer.start(f"cell_fwd[{kind}]")
         check(lib.sparch_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                   ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0), ptr(w0),
                                   ptr(s0), theta, p_drop, seed, ptr(s_out), ptr(u_save), ptr(w_save),
                                   ptr(count), _stream()), "sparch_cell_fwd")
+        timer.stop(tok)
     else:
         if H % 4 != 0:
             raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
@@ -214,11 +260,13 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+        tok = timer.start(f"rec_cell_fwd[{kind}]")
         check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                       ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
                                       ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
                                       ptr(u_save), ptr(w_save), ptr(count), ptr(chan), nbytes,
                                       ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
+        timer.stop(tok)
     return s_out, count, (u_save, w_save)
 
 
@@ -236,10 +284,12 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     ws = torch.empty(n_planes, Bp, H, dtype=torch.float32, device=dev)
     grads = {}
     if not recurrent:
+        tok = timer.start(f"cell_bwd[{kind}]")
         check(lib.sparch_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
                                   ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0),
                                   ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(ws), _stream()),
               "sparch_cell_bwd")
+        timer.stop(tok)
     else:
         V = p["V"]
         vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
@@ -248,11 +298,13 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+        tok = timer.start(f"rec_cell_bwd[{kind}]")
         check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
                                       ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
                                       ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
                                       ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
                                       _stream()), "sparch_rec_cell_bwd")
+        timer.stop(tok)
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712)
         grads["V"] = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True)
     names = ["alpha"] + (["beta", "a", "b"] if adaptive else [])
