@@ -55,7 +55,11 @@ def cpu_baseline(rank):
     """The oracle on the host cores, bounded sample of the same workload (same model, B=64 of 256)."""
     from oracle import snn_oracle as orc
 
-    n_threads = os.cpu_count() or 1
+    try:
+        n_threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_threads = os.cpu_count() or 1
+    n_threads = max(1, min(n_threads, 16))  # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(n_threads)
     Bs, T, C = 64, WORKLOAD["T"], WORKLOAD["C"]
     sizes = WORKLOAD["layer_sizes"]
@@ -181,6 +185,8 @@ def main():
                 ach = amount / avg_s / 1e9
                 roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": kern[dom]["avg_ms"]}
+        print(f"[bench] gpu: {value:.0f} ts*samples/s, {ms:.2f} ms/step; dominant {dom}; "
+              f"timing the CPU oracle sample next", file=sys.stderr, flush=True)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(rank)

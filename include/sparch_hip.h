@@ -46,6 +46,8 @@ extern "C" {
 
 int sparch_abi_version(void);
 const char* sparch_strerror(int code);
+/* Text of the HIP error behind the calling thread's most recent SPARCH_ELAUNCH. */
+const char* sparch_last_hip_error(void);
 /* Number of compute units / XCDs the library sizes its persistent grids for. */
 int sparch_device_cus(void);
 

@@ -23,6 +23,7 @@ P = c_void_p  # device (or host-array) pointer
 PROTOTYPES = {
     "sparch_abi_version": (c_int, []),
     "sparch_strerror": (c_char_p, [c_int]),
+    "sparch_last_hip_error": (c_char_p, []),
     "sparch_device_cus": (c_int, []),
     "sparch_gemm_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
@@ -86,6 +87,8 @@ def check(code, what):
     if code == SPARCH_OK:
         return
     msg = f"{what}: {strerror(code)} (code {code})"
+    if code == -4:
+        msg += f" [HIP: {lib.sparch_last_hip_error().decode()}]"
     if code in (-1, -2):
         raise ValueError(msg)
     raise SparchHipError(msg)

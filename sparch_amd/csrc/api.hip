@@ -1,7 +1,14 @@
 // ABI bookkeeping entry points of libsparch_hip.so.
 #include "common.h"
 
+static thread_local int g_last_hip_error = 0;
+void sparch_note_hip_error(int e) { g_last_hip_error = e; }
+
 extern "C" int sparch_abi_version(void) { return 1; }
+
+extern "C" const char* sparch_last_hip_error(void) {
+    return hipGetErrorString((hipError_t)g_last_hip_error);
+}
 
 extern "C" const char* sparch_strerror(int code) {
     switch (code) {
@@ -16,6 +23,7 @@ extern "C" const char* sparch_strerror(int code) {
 }
 
 extern "C" int sparch_device_cus(void) {
+    SPARCH_ENTER();
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;

@@ -348,6 +348,7 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
                                const float* w0, const float* s0, float theta, float p_drop,
                                uint64_t seed, float* s_out, float* u_save, float* w_save,
                                uint32_t* spike_count, void* stream) {
+    SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_ADLIF;
     if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !Wx || !alpha || !u0 || !s0 || !s_out)
@@ -372,6 +373,7 @@ extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const fl
                                const float* alpha, const float* beta, const float* a, const float* b,
                                const float* u0, const float* w0, const float* s0, float theta,
                                float p_drop, uint64_t seed, float* dWx, float* dparam_ws, void* stream) {
+    SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_ADLIF;
     if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !g_out || !u_save || !alpha || !u0 ||
@@ -395,6 +397,7 @@ extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const fl
 extern "C" int sparch_readout_fwd(int B, int T, int C, const float* Wx, const float* scale,
                                   const float* shift, const float* alpha, const float* u0, float* out,
                                   float* u_save, void* stream) {
+    SPARCH_ENTER();
     if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !Wx || !alpha || !u0 || !out) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
     hipLaunchKernelGGL(readout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, B, T, C, Wx,
@@ -407,6 +410,7 @@ extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const
                                   const float* scale, const float* shift, const float* u_save,
                                   const float* alpha, const float* u0, float* dWx, float* dalpha_ws,
                                   void* stream) {
+    SPARCH_ENTER();
     (void)Wx; (void)scale; (void)shift;  // dalpha uses u_{t-1}-x_t = (u_{t-1}-u_t)/(1-alpha): no re-read of Wx
     if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
         return SPARCH_EINVAL;

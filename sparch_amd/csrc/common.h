@@ -8,9 +8,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hipGetLastError() is sticky per thread and other HIP users in the process (the PyTorch runtime)
+// may leave a benign error behind: every entry point clears it first (SPARCH_ENTER), then each
+// launch is checked and the real HIP error kept for sparch_last_hip_error().
+void sparch_note_hip_error(int hip_error);
+#define SPARCH_ENTER() (void)hipGetLastError()
 #define SPARCH_CHECK_LAUNCH()                          \
     do {                                               \
-        if (hipGetLastError() != hipSuccess) return SPARCH_ELAUNCH; \
+        hipError_t e_ = hipGetLastError();             \
+        if (e_ != hipSuccess) { sparch_note_hip_error((int)e_); return SPARCH_ELAUNCH; } \
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -112,11 +112,13 @@ __global__ __launch_bounds__(256) void fbank_kernel(int n_clips, int n_samples, 
 }  // namespace
 
 extern "C" int sparch_fbank_frames(int n_samples) {
+    SPARCH_ENTER();
     return n_samples < FRAME ? 0 : 1 + (n_samples - FRAME) / SHIFT;
 }
 
 extern "C" int sparch_fbank_fwd(int n_clips, int n_samples, int n_mels, const float* wave, float* out,
                                 void* stream) {
+    SPARCH_ENTER();
     const int n_frames = sparch_fbank_frames(n_samples);
     if (n_clips <= 0 || n_frames <= 0 || n_mels <= 0 || n_mels > 256 || !wave || !out) return SPARCH_EINVAL;
     hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)(n_clips * n_frames)), dim3(256), 0, (hipStream_t)stream,

@@ -246,6 +246,7 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
 
 extern "C" int sparch_gemm_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, const float* bias, float* colstat_ws, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
@@ -261,6 +262,7 @@ extern "C" int sparch_gemm_nt(int M, int N, int K, const float* A, int lda, cons
 
 extern "C" int sparch_gemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
@@ -279,6 +281,7 @@ extern "C" size_t sparch_gemm_tn_workspace_bytes(int M, int N, int K) {
 
 extern "C" int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, int zero_diag, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int splits = choose_splits(M, N, K);

@@ -249,6 +249,7 @@ extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const floa
                                   float* running_var, float momentum, float eps, int training,
                                   float* scale, float* shift, float* save_mean, float* save_invstd,
                                   void* stream) {
+    SPARCH_ENTER();
     if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
     if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, H, M,
@@ -266,6 +267,7 @@ extern "C" size_t sparch_bn_bwd_workspace_bytes(int M, int H) {
 extern "C" int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* x, const float* mean,
                                     const float* invstd, float* dgamma, float* dbeta, void* ws,
                                     size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || H <= 0 || !dy || !x || !mean || !invstd || !dgamma || !dbeta) return SPARCH_EINVAL;
     if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
     if (!aligned16(dy) || !aligned16(x)) return SPARCH_EALIGN;
@@ -283,6 +285,7 @@ extern "C" int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* 
 extern "C" int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x, const float* mean,
                                    const float* invstd, const float* gamma, const float* dgamma,
                                    const float* dbeta, float* dx, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || H <= 0 || !dy || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx)
         return SPARCH_EINVAL;
     const size_t n = (size_t)M * H;
@@ -301,6 +304,7 @@ extern "C" int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x
 
 extern "C" int sparch_layernorm_fwd(int M, int H, const float* x, const float* gamma, const float* beta,
                                     float eps, float* y, float* mu, float* rstd, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || H <= 0 || !x || !gamma || !beta || !y || !mu || !rstd) return SPARCH_EINVAL;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, H, x,
                        gamma, beta, eps, y, mu, rstd);
@@ -311,6 +315,7 @@ extern "C" int sparch_layernorm_fwd(int M, int H, const float* x, const float* g
 extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const float* mu,
                                     const float* rstd, const float* gamma, float* dx, float* dgamma,
                                     float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || H <= 0 || !dy || !x || !mu || !rstd || !gamma || !dx || !dgamma || !dbeta) return SPARCH_EINVAL;
     if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
     if (!aligned16(dy) || !aligned16(x)) return SPARCH_EALIGN;
@@ -331,6 +336,7 @@ extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* 
 
 extern "C" int sparch_colsum(int M, int H, const float* x, float* out, void* ws, size_t ws_bytes,
                              void* stream) {
+    SPARCH_ENTER();
     if (M <= 0 || H <= 0 || !x || !out) return SPARCH_EINVAL;
     if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
     if (!aligned16(x)) return SPARCH_EALIGN;
@@ -346,6 +352,7 @@ extern "C" int sparch_colsum(int M, int H, const float* x, float* out, void* ws,
 }
 
 extern "C" int sparch_add_halves(size_t n, const float* x, float* out, void* stream) {
+    SPARCH_ENTER();
     if (n == 0 || !x || !out) return SPARCH_EINVAL;
     hipLaunchKernelGGL(add_halves_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        n, x, out);
@@ -356,6 +363,7 @@ extern "C" int sparch_add_halves(size_t n, const float* x, float* out, void* str
 extern "C" int sparch_colsum_clamped(int n_params, int rows, int H, const float* ws,
                                      const float* const* raw, const float* lim_lo_hi, float* const* out,
                                      void* stream) {
+    SPARCH_ENTER();
     if (n_params < 1 || n_params > 4 || rows <= 0 || H <= 0 || !ws || !out) return SPARCH_EINVAL;
     ClampArgs a{};
     for (int j = 0; j < n_params; ++j) {

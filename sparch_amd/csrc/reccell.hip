@@ -603,6 +603,7 @@ extern "C" size_t sparch_vpack_bytes(int H) {
 }
 
 extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked, void* stream) {
+    SPARCH_ENTER();
     const int kgw = pick_kgw(H);
     if (H <= 0 || kgw == 0 || !V || !vpack) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -633,6 +634,7 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
                                    uint64_t seed, float* s_out, float* u_save, float* w_save,
                                    uint32_t* spike_count, void* chan, size_t chan_bytes,
                                    uint32_t* status, int steps_per_launch, void* stream) {
+    SPARCH_ENTER();
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
@@ -660,6 +662,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
                                    uint64_t seed, float* dWx, float* s_prev, float* dparam_ws,
                                    void* chan, size_t chan_bytes, uint32_t* status,
                                    int steps_per_launch, void* stream) {
+    SPARCH_ENTER();
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;

@@ -196,43 +196,53 @@ def test_recurrent_backward_vs_oracle_autograd(kind):
 
 @pytest.mark.parametrize("spl", [1, None])
 @pytest.mark.parametrize("kind,Bp,T,H", [("RLIF", 48, 60, 128), ("RadLIF", 96, 80, 256), ("RadLIF", 33, 40, 1024)])
-def test_recurrent_first_divergence_is_at_threshold(kind, Bp, T, H, spl):
-    """Real-valued orthogonal V: the MFMA's k-order differs from a CPU sgemm's, so u can differ in
-    the last bits and a spike may flip when u is within rounding of theta; after that the sample's
-    trajectory legitimately separates.  Rigorous check: for every sample, everything BEFORE its
-    first mismatching step is bit-identical, and AT the first mismatch the oracle's own membrane
-    potential of every mismatching neuron lies within 5e-5 of the threshold."""
+def test_recurrent_one_step_ahead_vs_oracle_trajectory(kind, Bp, T, H, spl):
+    """Real-valued orthogonal V (the reference's init).  The MFMA's k-order differs from a CPU
+    sgemm's, so `s@V` differs in the last bits; the reference's own subthreshold (u,w) map is
+    expansive for a -> -1 (eigenvalue ~1.4 per step), so free-running trajectories separate
+    exponentially whatever the implementation.  The rigorous check is therefore teacher-forced:
+    every (sample, t) of a long ORACLE trajectory becomes an independent 2-step problem started
+    from the oracle's exact state (u,w,s)_{t-1}.  Step 0 exercises the rec0 GEMM path, step 1
+    the in-kernel MFMA + spike hand-off.  A spike may differ from the oracle's only where the
+    oracle's own membrane potential is within 1e-4 of the threshold."""
     from oracle import bptt_numpy as bp
     Fn = _Fn()
     g = torch.Generator().manual_seed(17 + H)
     V = torch.nn.init.orthogonal_(torch.empty(H, H), generator=g)
-    Wx = torch.randn(Bp, T, H, generator=g) * 1.2 + 0.2
+    Wx = torch.randn(Bp, T, H, generator=g) * 1.5 + 0.5
     p = {"alpha": torch.rand(H, generator=g) * 0.14 + 0.82, "V": V}
     if kind == "RadLIF":
         p.update(beta=torch.rand(H, generator=g) * 0.024 + 0.967, a=torch.rand(H, generator=g) * 2 - 1,
                  b=torch.rand(H, generator=g) * 2)
     u0, s0 = torch.rand(Bp, H, generator=g), torch.rand(Bp, H, generator=g)
     w0 = torch.rand(Bp, H, generator=g) if kind == "RadLIF" else None
-    S, U, _ = bp.cell_forward(kind, Wx.numpy(), {k: v.numpy() for k, v in p.items()}, u0.numpy(),
-                              None if w0 is None else w0.numpy(), s0.numpy())
+    pn = {k: v.numpy() for k, v in p.items()}
+    S, U, W = bp.cell_forward(kind, Wx.numpy(), pn, u0.numpy(), None if w0 is None else w0.numpy(), s0.numpy())
+    assert S.mean() > 0.003
+    # pseudo-samples: state after step t-1, inputs of steps t and t+1, for t = 1 .. T-2
+    ts = np.arange(1, T - 1)
+    u_in = torch.from_numpy(U[:, ts - 1].reshape(-1, H).copy())
+    s_in = torch.from_numpy(S[:, ts - 1].reshape(-1, H).copy())
+    w_in = torch.from_numpy(W[:, ts - 1].reshape(-1, H).copy()) if W is not None else None
+    Wx2 = torch.from_numpy(np.stack([Wx.numpy()[:, ts], Wx.numpy()[:, ts + 1]], axis=2).reshape(-1, 2, H).copy())
+    ref_s = np.stack([S[:, ts], S[:, ts + 1]], axis=2).reshape(-1, 2, H)
+    ref_u = np.stack([U[:, ts], U[:, ts + 1]], axis=2).reshape(-1, 2, H)
     pd = {k: v.to(DEV) for k, v in p.items()}
-    s = Fn.SpikingCellFn.apply(kind, 1.0, Wx.to(DEV), pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"),
-                               pd["V"], u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), spl)
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wx2.to(DEV), pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"),
+                               pd["V"], u_in.to(DEV), None if w_in is None else w_in.to(DEV), s_in.to(DEV), spl)
     Fn.check_status()
     s = s.cpu().numpy()
-    assert S.mean() > 0.01
-    diff = s != S
-    n_div = 0
-    for b in range(Bp):
-        steps = np.nonzero(diff[b].any(axis=1))[0]
-        if steps.size == 0:
-            continue
-        n_div += 1
-        t0 = int(steps[0])
-        margin = np.abs(U[b, t0][diff[b, t0]] - 1.0)
-        assert margin.max() <= 5e-5, (b, t0, margin.max())
-    print(f"{kind} H={H}: {n_div}/{Bp} samples flipped at a near-threshold potential")
-    assert n_div <= max(2, Bp // 2)
+    diff = s != ref_s
+    n0, n1 = int(diff[:, 0].sum()), int(diff[:, 1].sum())
+    if diff[:, 0].any():
+        assert np.abs(ref_u[:, 0][diff[:, 0]] - 1.0).max() <= 1e-4
+    # step 1 inherits step 0's (legitimate) flips: only judge rows whose step 0 agreed
+    ok_rows = ~diff[:, 0].any(axis=1)
+    d1 = diff[:, 1] & ok_rows[:, None]
+    if d1.any():
+        assert np.abs(ref_u[:, 1][d1] - 1.0).max() <= 1e-4
+    print(f"{kind} H={H}: {n0}+{n1} near-threshold flips in {ref_s.size} spikes")
+    assert (n0 + n1) <= 1e-4 * ref_s.size + 2
 
 
 @pytest.mark.parametrize("norm", ["batchnorm", "layernorm"])
@@ -328,8 +338,9 @@ def test_snn_train_step_vs_reference_golden(sp, name):
         for k, v in net.named_parameters():
             assert bool(torch.isfinite(v.grad).all()), k
     for k, v in net.state_dict().items():
-        if "running" in k:
-            np.testing.assert_allclose(v.cpu().numpy(), z["after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+        if "running" in k:  # layers fed by a recurrent layer see a (legitimately) different spike train
+            tol = 5e-3 if (recurrent and not k.startswith("snn.0.")) else 1e-5
+            np.testing.assert_allclose(v.cpu().numpy(), z["after." + k], rtol=1e-4, atol=tol, err_msg=k)
     net.eval()
     with torch.no_grad():
         torch.manual_seed(cfg["fwd_seed"])
@@ -364,7 +375,7 @@ def test_dropout_statistics_and_backward_mask_consistency(sp):
     lay.dropout = 0.25
     s_drop, rate = s_drop.detach(), rate.detach()
     vals = torch.unique(s_drop)
-    assert set(np.round(vals.cpu().numpy(), 5).tolist()) <= {0.0, round(1 / 0.75, 5)}
+    assert all(min(abs(v), abs(v - 1 / 0.75)) < 1e-6 for v in vals.cpu().tolist()), vals
     fired = s_full > 0
     kept = (s_drop > 0)[fired].float().mean().item()
     assert abs(kept - 0.75) < 0.02, kept
