@@ -10,6 +10,12 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 
+# PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be in the
+# process BEFORE libsparch_hip.so is dlopen'ed so that both bind ONE HIP runtime (one device
+# context, shared streams and allocations); loaded the other way round our kernels would be
+# registered with a second, device-less runtime ("no ROCm-capable device is detected").
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsparch_hip.so")
 
@@ -68,6 +74,17 @@ def _load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C sparch_amd/csrc`."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    runtimes = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    runtimes.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    if len(runtimes) > 1:
+        raise ImportError(f"two HIP runtimes are mapped ({sorted(runtimes)}); libsparch_hip.so and "
+                          "PyTorch must share one libamdhip64")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = library/header mismatch: fail loudly
         fn.restype = res
