@@ -17,7 +17,7 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparch_hip.so")
+LIB_PATH = os.environ.get("SPARCH_HIP_LIB") or os.path.join(_HERE, "libsparch_hip.so")  # override: diagnostic builds
 
 SPARCH_OK = 0
 KIND = {"LIF": 0, "adLIF": 1, "RLIF": 2, "RadLIF": 3}

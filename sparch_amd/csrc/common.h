@@ -37,14 +37,18 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) {
     return fminf(fmaxf(x, lo), hi);
 }
 
-// Dropout decision for output element `idx` of a layer: a counter-based hash
-// (splitmix64 finaliser) of (seed, idx); keep iff uniform >= p.  Forward and
+// Dropout decision for output element `idx` of a layer: a counter-based hash of (seed, idx) built
+// from two rounds of a 32-bit integer finaliser (lowbias32); keep iff uniform >= p.  Forward and
 // backward regenerate the same mask from (seed, idx), nothing is stored.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24-bit uniform [0,1)
+    const uint32_t a = mix32((uint32_t)idx ^ (uint32_t)seed);
+    const uint32_t b = mix32(a + (uint32_t)(idx >> 32) * 0x9E3779B9U + (uint32_t)(seed >> 32));
+    const float u = (float)(b >> 8) * (1.0f / 16777216.0f);  // 24-bit uniform [0,1)
     return u >= p ? inv_keep : 0.0f;
 }

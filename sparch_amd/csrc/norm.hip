@@ -14,22 +14,40 @@ namespace {
 
 constexpr int RB = 256;  // rows per partial block in column reductions
 
+// Sum rows [0,n) of a row-major [n][ld] fp32 array for 64 adjacent columns per 256-thread block:
+// thread (c = tid&63, q = tid>>6) adds rows q, q+4, ... in fp64 (coalesced 256-B row segments),
+// the four row-lanes meet in LDS in a fixed order.  Returns the total to the q == 0 threads.
+__device__ __forceinline__ double col_sum64(const float* __restrict__ base, int n, size_t ld, int col, bool ok,
+                                            double (*red)[64]) {
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double s = 0.0;
+    if (ok)
+        for (int r = q; r < n; r += 4) s += (double)base[(size_t)r * ld + col];
+    red[q][c] = s;
+    __syncthreads();
+    const double tot = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    __syncthreads();
+    return tot;
+}
+
 // ---------------------------------------------------------------- BatchNorm forward
-__global__ void bn_finalize_kernel(int H, int M, int n_tiles, int dup, const float* __restrict__ ws,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_tiles, int dup, const float* __restrict__ ws,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
+    __shared__ double red[4][64];
+    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool ok = h < H;
+    double s = 0.0, ss = 0.0;
+    if (training) {
+        s = col_sum64(ws, n_tiles, H, h, ok, red);
+        ss = col_sum64(ws + (size_t)n_tiles * H, n_tiles, H, h, ok, red);
+    }
+    if (!ok || threadIdx.x >= 64) return;
     float mean, var;
     if (training) {
-        double s = 0.0, ss = 0.0;
-        for (int t = 0; t < n_tiles; ++t) {
-            s += (double)ws[(size_t)t * H + h];
-            ss += (double)ws[(size_t)(n_tiles + t) * H + h];
-        }
         const double mu = s / (double)M;
         double v = ss / (double)M - mu * mu;
         if (v < 0.0) v = 0.0;
@@ -110,15 +128,15 @@ __global__ __launch_bounds__(256) void colpartial_kernel(int M, int H, const flo
     }
 }
 
-__global__ void colfinish_kernel(int H, int n_rb, int n_out, const float* __restrict__ ws,
-                                 float* __restrict__ out0, float* __restrict__ out1) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r < n_rb; ++r) {
-        s0 += (double)ws[(size_t)r * H + h];
-        if (n_out > 1) s1 += (double)ws[(size_t)(n_rb + r) * H + h];
-    }
+__global__ __launch_bounds__(256) void colfinish_kernel(int H, int n_rb, int n_out, const float* __restrict__ ws,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double red[4][64];
+    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool ok = h < H;
+    const double s0 = col_sum64(ws, n_rb, H, h, ok, red);
+    double s1 = 0.0;
+    if (n_out > 1) s1 = col_sum64(ws + (size_t)n_rb * H, n_rb, H, h, ok, red);
+    if (!ok || threadIdx.x >= 64) return;
     out0[h] = (float)s0;
     if (n_out > 1) out1[h] = (float)s1;
 }
@@ -226,14 +244,14 @@ struct ClampArgs {
     float lo[4], hi[4];
     int gated[4];
 };
-__global__ void colsum_clamped_kernel(int n_params, int rows, int H, const float* __restrict__ ws,
-                                      ClampArgs a) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_clamped_kernel(int n_params, int rows, int H,
+                                                             const float* __restrict__ ws, ClampArgs a) {
+    __shared__ double red[4][64];
+    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = blockIdx.y;
-    if (h >= H || j >= n_params) return;
-    const float* p = ws + (size_t)j * rows * H + h;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)p[(size_t)r * H];
+    const bool ok = h < H;
+    const double s = col_sum64(ws + (size_t)j * rows * H, rows, H, h, ok, red);
+    if (!ok || threadIdx.x >= 64) return;
     float v = (float)s;
     if (a.gated[j]) {
         const float x = a.raw[j][h];
@@ -252,7 +270,7 @@ extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const floa
     SPARCH_ENTER();
     if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
     if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, H, M,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, 64)), dim3(256), 0, (hipStream_t)stream, H, M,
                        n_tiles, dup, colstat_ws, gamma, beta, running_mean, running_var, momentum, eps,
                        training, scale, shift, save_mean, save_invstd);
     SPARCH_CHECK_LAUNCH();
@@ -276,7 +294,7 @@ extern "C" int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* 
     hipLaunchKernelGGL(colpartial_kernel<1>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mean,
                        invstd, (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
                        dbeta, dgamma);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -325,7 +343,7 @@ extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* 
     hipLaunchKernelGGL(colpartial_kernel<2>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mu, rstd,
                        (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
                        dbeta, dgamma);
     SPARCH_CHECK_LAUNCH();
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, M, H, dy, x, mu, rstd, gamma,
@@ -345,7 +363,7 @@ extern "C" int sparch_colsum(int M, int H, const float* x, float* out, void* ws,
     hipLaunchKernelGGL(colpartial_kernel<0>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, x, x,
                        (const float*)nullptr, (const float*)nullptr, (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, H, n_rb, 1, (const float*)ws, out,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 1, (const float*)ws, out,
                        (float*)nullptr);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -373,7 +391,7 @@ extern "C" int sparch_colsum_clamped(int n_params, int rows, int H, const float*
         a.gated[j] = (raw && raw[j] && lim_lo_hi) ? 1 : 0;
         if (a.gated[j]) { a.lo[j] = lim_lo_hi[2 * j]; a.hi[j] = lim_lo_hi[2 * j + 1]; }
     }
-    hipLaunchKernelGGL(colsum_clamped_kernel, dim3(cdiv(H, 256), n_params), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_clamped_kernel, dim3(cdiv(H, 64), n_params), dim3(256), 0, (hipStream_t)stream,
                        n_params, rows, H, ws, a);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;

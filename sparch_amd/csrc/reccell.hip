@@ -9,18 +9,27 @@
 // Decomposition (gfx950, 256 CUs in 8 XCDs):
 //   * a workgroup (256 threads, one wave per SIMD) owns a 32-row x 32-column tile of the
 //     (B', H) state for the whole sequence; membrane/adaptation state lives in registers;
-//   * its 1024x32 slice of V (forward) / V^T (backward) is resident in VGPRs for the whole
-//     launch as MFMA B-operands (128 VGPRs per wave at H=1024); the four waves split K and
-//     the partial 32x32 tiles meet in LDS (fixed order => reproducible);
+//   * its 1024x32 slice of V (forward) / V^T (backward) stays in VGPRs for the whole launch
+//     as MFMA B-operands; the four waves split K and the partial 32x32 tiles meet in LDS in
+//     a fixed order (reproducible);
+//   * EXACT low-precision operands: every fp32 V element is split into three bf16 values
+//     V = hi + mid + lo (8+8+8 significand bits, exact).  Spikes are 0/1, exact in bf16, so
+//     s@V = s@hi + s@mid + s@lo runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with
+//     exact products and fp32 accumulation: same accuracy class as an fp32 fmaf chain at 3/16
+//     of its cost.  In the backward dWx is split the same way by its producer and the six
+//     largest cross terms (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are
+//     <= 2^-24 relative) are accumulated: fp32-faithful at 6/16 of the fp32 MFMA cost;
 //   * the 32 workgroups of one batch tile exchange the step's output every step:
 //       forward  — spikes, bit-packed, as 8-byte {tag = t+1, 32 spike bits} granules written
 //                  with one agent-scope (sc1, write-through) store each and polled with sc1
-//                  loads: the data is the flag, no fence (MI355X guide, G16 form R2);
-//       backward — the 32x32 fp32 tile of dWx_t, stored straight into the dWx output tensor
-//                  with 16-byte sc1 stores, drained (vmcnt(0)) + workgroup barrier, then one
-//                  sc1 flag store; consumers poll the flag and read the tile with sc1 loads
-//                  (G16 form R1).  No slot is ever reused inside a call (one slot per time
-//                  step), so there is no back-pressure protocol;
+//                  loads: the data is the flag, no fence (MI355X guide, G16 form R2).  One slot
+//                  per (step, row): never reused inside a call;
+//       backward — the tile of dWx_t as three bf16 planes, 8-byte sc1 stores into a depth-4
+//                  ring, drained (vmcnt(0)) + workgroup barrier, then one sc1 tag store
+//                  (tag = T - t); consumers poll the tag and read the planes with 16-byte sc1
+//                  loads (G16 form R1).  Lock-step makes depth 2 sufficient: a workgroup writes
+//                  step t-1 only after it has read every peer's step t, which they produced
+//                  after reading every step t+1 tile;
 //   * block -> tile mapping keeps a batch tile's workgroups at equal blockIdx % n_row_tiles,
 //     i.e. on one XCD under round-robin dispatch.  That is a speed choice only: every
 //     hand-off is agent-scope and placement-independent.  Every spin is bounded by a
@@ -28,19 +37,21 @@
 //   * steps_per_launch = T gives one persistent launch; = 1 degenerates to one launch per
 //     time step, where every wait is already satisfied at launch (safe fallback, and the
 //     path for shapes whose grid cannot be co-resident).
-// MFMA: v_mfma_f32_32x32x2_f32, exact fp32 products; A = spikes (0/1) or dWx, B = V slice.
 #include "common.h"
 
 namespace {
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr int RT = 32;       // rows per batch tile
 constexpr int CT = 32;       // columns per workgroup (= one k-group of its consumers)
 constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
+constexpr int RING = 4;      // depth of the backward hand-off ring (2 suffices, see header)
 constexpr u64 TIMEOUT_TICKS = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
 struct RecArgs {
@@ -50,7 +61,7 @@ struct RecArgs {
     int t_begin, t_end;
     const float* Wx; const float* scale; const float* shift;
     const float* alpha; const float* beta; const float* a; const float* b;
-    const float* vpack; const float* rec0;
+    const u32x4* vpack; const float* rec0;
     const float* u0; const float* w0; const float* s0;
     float theta, p_drop, inv_keep; uint64_t seed;
     float* s_out; float* u_save; float* w_save; uint32_t* spike_count;
@@ -58,8 +69,31 @@ struct RecArgs {
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; float* s_prev; float* dparam_ws;
     // hand-off
-    u64* chan; unsigned* flags; unsigned* status;
+    u64* chan; unsigned* flags; unsigned short* planes; unsigned* status;
 };
+
+// Diagnostic build only (-DSPARCH_REC_PROF, never shipped): per-workgroup sums of s_memtime
+// deltas for the segments of a time step, written to a private buffer no kernel reads.
+#ifdef SPARCH_REC_PROF
+__device__ u64 g_rec_prof[2][512][8];
+#define PROF_DECL u64 pf_t = 0, pf_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PROF_STAMP(i)                                                                           \
+    do {                                                                                        \
+        u64 now_;                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if ((i) >= 0) pf_acc[(i) < 0 ? 0 : (i)] += now_ - pf_t;                                 \
+        pf_t = now_;                                                                            \
+    } while (0)
+#define PROF_FLUSH(which)                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 512)                                                   \
+        for (int i_ = 0; i_ < 6; ++i_) g_rec_prof[which][blockIdx.x][i_] += pf_acc[i_];
+#else
+#define PROF_DECL
+#define PROF_STAMP(i)
+#define PROF_FLUSH(which)
+#endif
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -69,10 +103,43 @@ __device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot)
     *(volatile int*)abort_slot = 1;
 }
 
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+
+// exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (round-to-nearest-even at each step)
+__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(unsigned short, h);
+    mid = __builtin_bit_cast(unsigned short, m);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// V (or V^T) slice -> registers: per k-group, 2 k16-steps x 3 planes of 8 bf16 (4 VGPRs) each
+template <int KGW>
+__device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4* __restrict__ vpack, int ct,
+                                            int nkg, int wave, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < KGW; ++kk) {
+        const int kg = wave + 4 * kk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                vb[kk][ks][p] = vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane];
+    }
+}
+
 // ------------------------------------------------------------------------------ forward
 template <bool ADAPT, int KGW>
 __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][4][RT * RED_LD];
+    __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
     __shared__ int abort_flag[2];
     __shared__ unsigned cnt_lds[2][CT];
 
@@ -91,17 +158,14 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    // V slice -> registers (B operand of the 32x32x2 MFMA: lane = (column li, k-half hh))
-    float vreg[KGW][16];
+    u32x4 vb[KGW][2][3];
+    load_vslice<KGW>(vb, a.vpack, ct, a.nkg, wave, lane);
+    {
+        u32x4 e;
 #pragma unroll
-    for (int kk = 0; kk < KGW; ++kk) {
-        const int kg = wave + 4 * kk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = ld4(a.vpack + ((((size_t)ct * a.nkg + kg) * 4 + q) * 64 + lane) * 4);
-            vreg[kk][4 * q + 0] = v.x; vreg[kk][4 * q + 1] = v.y;
-            vreg[kk][4 * q + 2] = v.z; vreg[kk][4 * q + 3] = v.w;
-        }
+        for (int j = 0; j < 4; ++j)
+            e[j] = (((unsigned)tid >> (2 * j)) & 1u ? 0x3F80u : 0u) | (((unsigned)tid >> (2 * j + 1)) & 1u ? 0x3F800000u : 0u);
+        lut[tid] = e;
     }
 
     float al[4], oma[4], be[4], pa[4], pb[4], sc[4], sh[4], u[4], w[4], s[4];
@@ -142,8 +206,10 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         return a.Wx + ((size_t)b * T + tt) * H + colc;
     };
     f32x4 x_next = ld4(wx_ptr(a.t_begin));
+    PROF_DECL
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
+        PROF_STAMP(-1);
         const f32x4 xv = x_next;
         if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
@@ -177,6 +243,16 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+            PROF_STAMP(0);  // poll wait
+            // ---- s_{t-1} @ V on the bf16 MFMA: spikes expanded through the LDS table (lane
+            //      (row li, k-half hh) takes byte 2*ks + hh of its row's 32-bit word)
+            u32x4 af[KGW][2];
+#pragma unroll
+            for (int kk = 0; kk < KGW; ++kk) {
+                const unsigned wbits = (unsigned)gran[kk];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[kk][ks] = lut[(wbits >> (16 * ks + 8 * hh)) & 0xFFu];
+            }
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -184,12 +260,10 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             for (int kk = 0; kk < KGW; ++kk) {
                 const int kg = wave + 4 * kk;
                 if (kg < a.n_ct) {
-                    const unsigned bits = ((unsigned)gran[kk]) >> (16 * hh);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float av = ((bits >> i) & 1u) ? 1.0f : 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vreg[kk][i], acc, 0, 0, 0);
-                    }
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int p = 2; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
                 }
             }
             float* rd = red[t & 1][wave];
@@ -198,8 +272,10 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 rd[row * RED_LD + li] = acc[i];
             }
+            PROF_STAMP(1);  // expand + MFMA + LDS write
         }
         __syncthreads();
+        PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
         if (t > 0) {
 #pragma unroll
@@ -210,10 +286,8 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         }
 
         // ---- pointwise membrane update for this thread's 4 neurons
-        const int tt = d ? (T - 1 - t) : t;
-        const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        f32x4 so, uo, wo;
+        f32x4 uo, wo;
         unsigned nib = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -226,21 +300,12 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             }
             u[e] = al[e] * (u[e] - s[e]) + oma[e] * drive;                  // snns.py:572 / 719
             s[e] = (u[e] - a.theta) > 0.0f ? 1.0f : 0.0f;                   // snns.py:29
-            const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
-            so[e] = s[e] * k;
             uo[e] = u[e];
             wo[e] = w[e];
-            if (valid) {
-                cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
-                nib |= (s[e] != 0.0f ? 1u : 0u) << e;
-            }
+            if (valid) nib |= (s[e] != 0.0f ? 1u : 0u) << e;
         }
-        if (valid) {
-            st4(a.s_out + o_out, so);
-            st4(a.u_save + ((size_t)bp * T + t) * H + col, uo);
-            if (ADAPT) st4(a.w_save + ((size_t)bp * T + t) * H + col, wo);
-        }
-        // ---- publish this tile's spikes: one tagged granule per row
+        // ---- publish this tile's spikes first (it is on every consumer's critical path): one
+        //      tagged granule per row; dropout and the bulk stores then overlap the peers' step
         unsigned word = nib << (cq * 4);
         word |= __shfl_xor(word, 1);
         word |= __shfl_xor(word, 2);
@@ -250,7 +315,24 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
+        PROF_STAMP(3);  // pointwise + publish
+        if (valid) {
+            const int tt = d ? (T - 1 - t) : t;
+            const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
+            f32x4 so;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+                so[e] = s[e] * k;
+                cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
+            }
+            st4(a.s_out + o_out, so);
+            st4(a.u_save + ((size_t)bp * T + t) * H + col, uo);
+            if (ADAPT) st4(a.w_save + ((size_t)bp * T + t) * H + col, wo);
+        }
+        PROF_STAMP(4);  // dropout + bulk stores issue
     }
+    PROF_FLUSH(0)
 
     // ---- spike counts (post-dropout) -> one integer atomic per (direction, column) per workgroup
     if (a.spike_count) {
@@ -272,6 +354,9 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
 template <bool ADAPT, int KGW>
 __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][4][RT * RED_LD];
+    // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
+    // hi/mid planes (128 VGPRs) plus all 48 in-flight dWx plane fragments (192 VGPRs) without spilling
+    __shared__ __attribute__((aligned(16))) u32x4 vlo[4][KGW][2][64];
     __shared__ int abort_flag[2];
 
     const int tid = threadIdx.x;
@@ -281,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     const int rt = a.rt_base + (int)(blockIdx.x % a.n_rt_launch);
     const int ct = (int)(blockIdx.x / a.n_rt_launch);
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
+    const int Hp = a.n_ct * CT;  // padded row length of the hand-off planes
 
     const int r = tid >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
@@ -288,30 +374,25 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    // A-operand row of this lane (row li of the batch tile), clamped into the tensor
-    const int arow = min(rt * RT + li, a.Bp - 1);
-    const int ad = arow / a.B;
-
-    // V^T slice -> registers
-    float vreg[KGW][16];
+    u32x4 vb[KGW][2][2];
 #pragma unroll
     for (int kk = 0; kk < KGW; ++kk) {
         const int kg = wave + 4 * kk;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = ld4(a.vpack + ((((size_t)ct * a.nkg + kg) * 4 + q) * 64 + lane) * 4);
-            vreg[kk][4 * q + 0] = v.x; vreg[kk][4 * q + 1] = v.y;
-            vreg[kk][4 * q + 2] = v.z; vreg[kk][4 * q + 3] = v.w;
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4* src = a.vpack + ((((size_t)ct * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
+            vb[kk][ks][0] = src[0];
+            vb[kk][ks][1] = src[64];
+            vlo[wave][kk][ks][lane] = src[128];
         }
     }
 
-    float al[4], oma[4], ioma[4], be[4], pa[4], pb[4], gr[4];
+    float al[4], oma[4], be[4], pa[4], pb[4], gr[4];
     float du_n[4], dw_n[4], u_t[4], acc_al[4], acc_be[4], acc_a[4], acc_b[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         al[e] = clampf(a.alpha[colc + e], SP_ALPHA_LO, SP_ALPHA_HI);
         oma[e] = 1.0f - al[e];
-        ioma[e] = 1.0f / oma[e];
         be[e] = ADAPT ? clampf(a.beta[colc + e], SP_BETA_LO, SP_BETA_HI) : 0.f;
         pa[e] = ADAPT ? clampf(a.a[colc + e], SP_A_LO, SP_A_HI) : 0.f;
         pb[e] = ADAPT ? clampf(a.b[colc + e], SP_B_LO, SP_B_HI) : 0.f;
@@ -339,11 +420,12 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     if (tid < 2) abort_flag[tid] = 0;
     __syncthreads();
 
-    // the dWx rows of this batch tile as a buffer resource (hand-off loads/stores carry sc1)
-    const int rows_here = min(RT, a.Bp - rt * RT);
-    float* tile_base = a.dWx + (size_t)rt * RT * T * H;
+    // hand-off ring: planes[slot][rt][p][row][Hp] bf16, one buffer resource for the whole ring
+    const size_t slot_elems = (size_t)a.n_rt_total * 3 * RT * Hp;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        tile_base, 0, (int)((size_t)rows_here * T * H * sizeof(float)), 0x00020000);
+        a.planes, 0, (int)(RING * slot_elems * sizeof(unsigned short)), 0x00020000);
+    const unsigned tile_off = (unsigned)(((size_t)rt * 3 * RT) * Hp * sizeof(unsigned short));  // bytes, plane 0 row 0
+    const unsigned plane_bytes = (unsigned)((size_t)RT * Hp * sizeof(unsigned short));
 
     const bool drop = a.p_drop > 0.0f;
     auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp) {
@@ -359,16 +441,21 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     };
     f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f};
     load_step(a.t_end - 1, g_nx, up_nx, wp_nx);
+    PROF_DECL
 
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
+        PROF_STAMP(-1);
         const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx;
         if (t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
 
         if (t + 1 < T) {
-            // ---- wait for dWx_{t+1} tiles of this wave's producers, then read them (sc1)
-            const gu32* fl = (const gu32*)a.flags + ((size_t)(t + 1) * a.n_rt_total + rt) * a.n_ct;
+            // ---- wait for the dWx_{t+1} tiles of this wave's producers (tag T-(t+1)), then read
+            //      their bf16 planes (sc1): all loads in flight before the first MFMA
+            const unsigned slot = (unsigned)((t + 1) % RING);
+            const unsigned want = (unsigned)(T - (t + 1));
+            const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
             const u64 t_start = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
@@ -376,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 for (int kk = 0; kk < KGW; ++kk) {
                     const int kg = wave + 4 * kk;
                     if (kg < a.n_ct)
-                        ok = ok && (__hip_atomic_load(fl + kg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+                        ok = ok && (__hip_atomic_load(fl + kg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want);
                 }
                 if (__all(ok)) break;
                 if ((spins & 63u) == 63u &&
@@ -386,8 +473,25 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            const int att = ad ? (T - 1 - (t + 1)) : (t + 1);
-            const unsigned row_off = (unsigned)(((size_t)(arow - rt * RT) * T + att) * H);
+            PROF_STAMP(0);  // flag wait
+            const unsigned base = (unsigned)(slot * slot_elems * sizeof(unsigned short)) + tile_off +
+                                  (unsigned)(((size_t)li * Hp + 8 * hh) * sizeof(unsigned short));
+            u32x4 af[KGW][2][3];
+#pragma unroll
+            for (int kk = 0; kk < KGW; ++kk) {
+                const int kg = wave + 4 * kk;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        if (kg < a.n_ct) {
+                            const unsigned off = base + p * plane_bytes + (unsigned)((kg * 32 + 16 * ks) * 2);
+                            af[kk][ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
+                        } else {
+                            af[kk][ks][p] = u32x4{0u, 0u, 0u, 0u};
+                        }
+                    }
+            }
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -395,20 +499,16 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             for (int kk = 0; kk < KGW; ++kk) {
                 const int kg = wave + 4 * kk;
                 if (kg < a.n_ct) {
-                    u32x4 av[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int kcol = kg * 32 + 16 * hh + 4 * q;
-                        const unsigned off = (row_off + (unsigned)min(kcol, H - 4)) * 4u;
-                        av[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
-                        if (kcol >= H) av[q] = u32x4{0u, 0u, 0u, 0u};
+                    for (int ks = 0; ks < 2; ++ks) {
+                        // six largest cross terms of (g_hi+g_mid+g_lo)(V_hi+V_mid+V_lo), small first
+                        acc = mfma_bf16(af[kk][ks][1], vb[kk][ks][1], acc);  // mid*mid
+                        acc = mfma_bf16(af[kk][ks][2], vb[kk][ks][0], acc);  // lo *hi
+                        acc = mfma_bf16(af[kk][ks][0], vlo[wave][kk][ks][lane], acc);  // hi *lo
+                        acc = mfma_bf16(af[kk][ks][1], vb[kk][ks][0], acc);  // mid*hi
+                        acc = mfma_bf16(af[kk][ks][0], vb[kk][ks][1], acc);  // hi *mid
+                        acc = mfma_bf16(af[kk][ks][0], vb[kk][ks][0], acc);  // hi *hi
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[q][e]),
-                                                                       vreg[kk][4 * q + e], acc, 0, 0, 0);
                 }
             }
             float* rd = red[par][wave];
@@ -417,8 +517,10 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 rd[row * RED_LD + li] = acc[i];
             }
+            PROF_STAMP(1);  // plane loads + MFMA + LDS write
         }
         __syncthreads();
+        PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[par]) break;
         if (t + 1 < T) {
 #pragma unroll
@@ -440,6 +542,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
         }
         f32x4 dwx, spv;
+        float du_new[4], dw_new[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
@@ -451,39 +554,63 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             const float box = (xs > -0.5f && xs <= 0.5f) ? 1.0f : 0.0f;       // snns.py:34-35
             float du = ds * box + al[e] * du_n[e];
             if (ADAPT) du = du + pa[e] * dw_n[e];
-            dwx[e] = oma[e] * du;
-            const float q = upv[e] - sp[e];
-            acc_al[e] += (du * (q - u_t[e])) * ioma[e];
-            if (ADAPT) {
-                const float dw = be[e] * dw_n[e] - dwx[e];
-                acc_be[e] += dw * wpv[e];
-                acc_a[e] += dw * upv[e];
-                acc_b[e] += dw * sp[e];
-                dw_n[e] = dw;
-            }
-            du_n[e] = du;
-            u_t[e] = upv[e];
+            dwx[e] = valid ? oma[e] * du : 0.0f;
+            du_new[e] = du;
+            dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
             spv[e] = sp[e];
         }
-        // ---- publish dWx_t (write-through), drain, barrier, flag
-        if (valid) {
-            const unsigned off = (unsigned)((((size_t)r * T + tt) * H + col) * sizeof(float));
-            u32x4 raw;
+        // ---- publish dWx_t first: three bf16 planes (write-through), drain, barrier, tag
+        if (t > 0) {
+            u32x2 pk[3];
+            unsigned short h0[4], m0[4], l0[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(dwx[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc, off, 0, 16 /* sc1 */);
-            st4(a.s_prev + ((size_t)bp * T + tt) * H + col, spv);
+            for (int e = 0; e < 4; ++e) split3(dwx[e], h0[e], m0[e], l0[e]);
+            pk[0] = u32x2{(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
+            pk[1] = u32x2{(unsigned)m0[0] | ((unsigned)m0[1] << 16), (unsigned)m0[2] | ((unsigned)m0[3] << 16)};
+            pk[2] = u32x2{(unsigned)l0[0] | ((unsigned)l0[1] << 16), (unsigned)l0[2] | ((unsigned)l0[3] << 16)};
+            const unsigned slot = (unsigned)(t % RING);
+            const unsigned off = (unsigned)(slot * slot_elems * sizeof(unsigned short)) + tile_off +
+                                 (unsigned)(((size_t)r * Hp + ct * CT + cq * 4) * sizeof(unsigned short));
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_raw_buffer_store_b64(pk[p], rsrc, off + p * plane_bytes, 0, 16 /* sc1 */);
         }
+        PROF_STAMP(3);  // pointwise + plane stores issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROF_STAMP(4);  // drain
         __syncthreads();
         if (tid == 0 && t > 0) {
-            gu32* f = (gu32*)a.flags + ((size_t)t * a.n_rt_total + rt) * a.n_ct + ct;
-            __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gu32* f = (gu32*)a.flags + ((size_t)(t % RING) * a.n_rt_total + rt) * a.n_ct + ct;
+            __hip_atomic_store(f, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
+        if (valid) {
+            st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
+            st4(a.s_prev + ((size_t)bp * T + tt) * H + col, spv);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float q = upv[e] - sp[e];
+            acc_al[e] += du_new[e] * (q - u_t[e]);  // x 1/(1-alpha) once, at the end
+            if (ADAPT) {
+                acc_be[e] += dw_new[e] * wpv[e];
+                acc_a[e] += dw_new[e] * upv[e];
+                acc_b[e] += dw_new[e] * sp[e];
+                dw_n[e] = dw_new[e];
+            }
+            du_n[e] = du_new[e];
+            u_t[e] = upv[e];
+        }
+        PROF_STAMP(5);  // barrier + tag + fp32 stores + partial sums
     }
+    PROF_FLUSH(1)
 
     if (valid) {
         f32x4 v;
+        if (a.t_begin == 0) {  // last chunk of the pass: d u_t / d alpha = (q - u_t) / (1 - alpha)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc_al[e] = acc_al[e] / oma[e];
+        }
         v.x = acc_al[0]; v.y = acc_al[1]; v.z = acc_al[2]; v.w = acc_al[3]; st4(ws, v);
         v.x = du_n[0]; v.y = du_n[1]; v.z = du_n[2]; v.w = du_n[3]; st4(ws + 4 * plane, v);
         if (ADAPT) {
@@ -496,19 +623,32 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
 }
 
 // ------------------------------------------------------------------------------ V prepack
-// vpack[ct][kg][q][lane][e] = Vm[k][col] (forward) or Vm[col][k] (backward), Vm = V with a
-// zero diagonal, k = kg*32 + 16*(lane>>5) + 4q + e, col = ct*32 + (lane&31); zero padded.
+// vpack[ct][kg][ks][p][lane] = 8 bf16 (16 B): plane p (0 hi, 1 mid, 2 lo) of Vm[k][col] (forward) or
+// Vm[col][k] (backward) for k = kg*32 + 16*ks + 8*(lane>>5) + j, j = 0..7, col = ct*32 + (lane&31);
+// Vm = V with a zero diagonal, zero padded.  This is the B-operand fragment of v_mfma_f32_32x32x16_bf16.
 __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const float* __restrict__ V,
-                             float* __restrict__ vpack) {
+                             u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)n_ct * nkg * 1024;
+    const size_t total = (size_t)n_ct * nkg * 2 * 64;
     if (idx >= total) return;
-    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), q = (int)((idx >> 8) & 3);
-    const int kg = (int)((idx >> 10) % nkg), ct = (int)((idx >> 10) / nkg);
-    const int k = kg * 32 + 16 * (lane >> 5) + 4 * q + e, col = ct * 32 + (lane & 31);
-    float v = 0.f;
-    if (k < H && col < H && k != col) v = transpose ? V[(size_t)col * H + k] : V[(size_t)k * H + col];
-    vpack[idx] = v;
+    const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 1);
+    const int kg = (int)((idx >> 7) % nkg), ct = (int)((idx >> 7) / nkg);
+    const int col = ct * 32 + (lane & 31);
+    unsigned short pl[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (k < H && col < H && k != col) v = transpose ? V[(size_t)col * H + k] : V[(size_t)k * H + col];
+        split3(v, pl[0][j], pl[1][j], pl[2][j]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (unsigned)pl[p][2 * q] | ((unsigned)pl[p][2 * q + 1] << 16);
+        vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane] = o;
+    }
 }
 __global__ void vmask_kernel(int H, const float* __restrict__ V, float* __restrict__ Vm) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,9 +659,20 @@ __global__ void vmask_kernel(int H, const float* __restrict__ V, float* __restri
 
 int pick_kgw(int H) {
     const int need = cdiv(cdiv(H, 32), 4);
-    for (int k : {1, 2, 4, 8, 16})
+    for (int k : {1, 2, 4, 8})
         if (need <= k) return k;
-    return 0;
+    return 0;  // H > 1024: V slice no longer fits the register file in this layout
+}
+
+size_t fwd_chan_bytes(int Bp, int T, int H) {
+    return (size_t)T * cdiv(Bp, RT) * cdiv(H, CT) * 32 * sizeof(u64);
+}
+size_t bwd_flag_bytes(int Bp, int H) {
+    const size_t b = (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * sizeof(unsigned);
+    return (b + 255) / 256 * 256;
+}
+size_t bwd_plane_bytes(int Bp, int H) {
+    return (size_t)RING * cdiv(Bp, RT) * 3 * RT * (cdiv(H, CT) * CT) * sizeof(unsigned short);
 }
 
 template <bool BWD, bool ADAPT>
@@ -534,7 +685,6 @@ int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
         case 2: SP_LAUNCH(2) break;
         case 4: SP_LAUNCH(4) break;
         case 8: SP_LAUNCH(8) break;
-        case 16: SP_LAUNCH(16) break;
         default: return SPARCH_EINVAL;
     }
 #undef SP_LAUNCH
@@ -550,10 +700,15 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     a.n_ct = cdiv(a.H, CT);
     a.nkg = 4 * kgw;
     a.n_rt_total = cdiv(a.Bp, RT);
-    const size_t need = sparch_rec_chan_bytes(a.Bp, a.T, a.H);
-    if (!a.chan || chan_bytes < need) return SPARCH_EWORKSPACE;
-    if (hipMemsetAsync(a.chan, 0, need, st) != hipSuccess) return SPARCH_ELAUNCH;
-    a.flags = reinterpret_cast<unsigned*>(a.chan);
+    if (!a.chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
+    if (!BWD) {
+        if (hipMemsetAsync(a.chan, 0, fwd_chan_bytes(a.Bp, a.T, a.H), st) != hipSuccess) return SPARCH_ELAUNCH;
+    } else {
+        const size_t fb = bwd_flag_bytes(a.Bp, a.H);
+        if (hipMemsetAsync(a.chan, 0, fb, st) != hipSuccess) return SPARCH_ELAUNCH;
+        a.flags = reinterpret_cast<unsigned*>(a.chan);
+        a.planes = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.chan) + fb);
+    }
 
     int L = steps_per_launch;
     if (L < 1) L = 1;
@@ -596,21 +751,31 @@ bool al16(std::initializer_list<const void*> ps) {
 
 }  // namespace
 
+#ifdef SPARCH_REC_PROF
+extern "C" int sparch_rec_prof_read(unsigned long long* host_out, int reset) {
+    static unsigned long long zero[2 * 512 * 8];
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rec_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_rec_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 extern "C" size_t sparch_vpack_bytes(int H) {
     const int kgw = pick_kgw(H);
     if (H <= 0 || kgw == 0) return 0;
-    return (size_t)cdiv(H, CT) * (4 * kgw) * 1024 * sizeof(float);
+    return (size_t)cdiv(H, CT) * (4 * kgw) * 2 * 3 * 64 * sizeof(u32x4);
 }
 
 extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked, void* stream) {
     SPARCH_ENTER();
     const int kgw = pick_kgw(H);
     if (H <= 0 || kgw == 0 || !V || !vpack) return SPARCH_EINVAL;
+    if (!aligned16(vpack)) return SPARCH_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int n_ct = cdiv(H, CT), nkg = 4 * kgw;
-    const size_t total = (size_t)n_ct * nkg * 1024;
+    const size_t total = (size_t)n_ct * nkg * 2 * 64;
     hipLaunchKernelGGL(vpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, H, n_ct, nkg,
-                       transpose, V, vpack);
+                       transpose, V, reinterpret_cast<u32x4*>(vpack));
     SPARCH_CHECK_LAUNCH();
     if (vmasked) {
         const size_t n = (size_t)H * H;
@@ -622,8 +787,9 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
 
 extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
-    // forward: T x row tiles x column tiles x 32 granules of 8 B (the backward's flags fit inside)
-    return (size_t)T * cdiv(Bp, RT) * cdiv(H, CT) * 32 * sizeof(u64);
+    // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: tags + bf16 plane ring
+    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_flag_bytes(Bp, H) + bwd_plane_bytes(Bp, H);
+    return f > b ? f : b;
 }
 
 extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
@@ -647,7 +813,7 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
     r.Wx = Wx; r.scale = scale; r.shift = shift;
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
-    r.vpack = vpack; r.rec0 = rec0; r.u0 = u0; r.w0 = w0; r.s0 = s0;
+    r.vpack = reinterpret_cast<const u32x4*>(vpack); r.rec0 = rec0; r.u0 = u0; r.w0 = w0; r.s0 = s0;
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
     r.s_out = s_out; r.u_save = u_save; r.w_save = w_save; r.spike_count = spike_count;
     r.chan = (u64*)chan; r.status = status;
@@ -671,12 +837,11 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
     if (!al16({g_out, u_save, w_save, vpack_t, u0, w0, s0, dWx, s_prev, dparam_ws, chan})) return SPARCH_EALIGN;
-    // the per-tile dWx window (32 rows x T x H floats) must be addressable by a 32-bit byte offset
-    if ((size_t)RT * T * H * sizeof(float) >= ((size_t)1 << 31)) return SPARCH_EINVAL;
+    if (bwd_plane_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
     RecArgs r{};
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
-    r.vpack = vpack_t; r.u0 = u0; r.w0 = w0; r.s0 = s0;
+    r.vpack = reinterpret_cast<const u32x4*>(vpack_t); r.u0 = u0; r.w0 = w0; r.s0 = s0;
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
     r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);

@@ -41,6 +41,14 @@ class SpikeFunctionBoxcar(torch.autograd.Function):
         return grad_spikes * inside.to(grad_spikes.dtype)
 
 
+def _rand_to(rows, cols, device):
+    """torch.rand from the global CPU generator (the reference's source of initial states), staged
+    in pinned memory and copied asynchronously so the host does not stall once per layer."""
+    if device.type == "cuda":
+        return torch.rand(rows, cols, pin_memory=True).to(device, non_blocking=True)
+    return torch.rand(rows, cols).to(device)
+
+
 def _make_norm(normalization, hidden_size):
     """BatchNorm1d(momentum=0.05) / LayerNorm / nothing (reference snns.py:238-244).  The
     torch modules only hold the parameters and running statistics; the maths runs in HIP."""
@@ -108,9 +116,9 @@ class _SpikingLayer(nn.Module):
         """Random initial u, [w], s from torch's global CPU generator, in the reference's
         order (snns.py:286-287, 423-425, 558-559, 700-702), then moved to the device."""
         H = self.hidden_size
-        u0 = torch.rand(rows, H).to(device)
-        w0 = torch.rand(rows, H).to(device) if self.kind in ("adLIF", "RadLIF") else None
-        s0 = torch.rand(rows, H).to(device)
+        u0 = _rand_to(rows, H, device)
+        w0 = _rand_to(rows, H, device) if self.kind in ("adLIF", "RadLIF") else None
+        s0 = _rand_to(rows, H, device)
         return u0, w0, s0
 
     def _dropout_seed(self, device):
@@ -231,7 +239,7 @@ class ReadoutLayer(nn.Module):
 
     def forward(self, x):
         Fn._require_device(x, "input")
-        u0 = torch.rand(x.shape[0], self.hidden_size).to(x.device)  # snns.py:812
+        u0 = _rand_to(x.shape[0], self.hidden_size, x.device)  # snns.py:812
         is_bn = self.normalization == "batchnorm"
         cfg = {
             "normalization": self.normalization if self.normalize else "none",
@@ -247,7 +255,7 @@ class ReadoutLayer(nn.Module):
 
     def _readout_cell(self, Wx):
         Fn._require_device(Wx, "Wx")
-        u0 = torch.rand(Wx.shape[0], Wx.shape[2]).to(Wx.device)
+        u0 = _rand_to(Wx.shape[0], Wx.shape[2], Wx.device)
         return Fn.ReadoutCellFn.apply(Wx, self.alpha, u0)
 
 

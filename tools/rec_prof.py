@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-step cycle breakdown of the recurrent cell kernels (needs `make -C sparch_amd/csrc prof`
+and SPARCH_HIP_LIB=sparch_amd/libsparch_hip_prof.so).  Prints average shader cycles per time step and segment
+for wave 0 of every workgroup."""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from sparch_amd import _capi  # noqa: E402
+from sparch_amd import functional as Fn  # noqa: E402
+
+B, T, H = 256, 250, 1024
+kind = sys.argv[1] if len(sys.argv) > 1 else "RadLIF"
+g = torch.Generator().manual_seed(0)
+dev = "cuda"
+V = torch.nn.init.orthogonal_(torch.empty(H, H), generator=g).to(dev)
+Wx = (torch.randn(B, T, H, generator=g) * 1.2 + 0.2).to(dev).requires_grad_(True)
+p = dict(alpha=torch.rand(H, generator=g) * 0.14 + 0.82, beta=torch.rand(H, generator=g) * 0.024 + 0.967,
+         a=torch.rand(H, generator=g) * 2 - 1, b=torch.rand(H, generator=g) * 2)
+p = {k: v.to(dev) for k, v in p.items()}
+u0, w0, s0 = (torch.rand(B, H, generator=g).to(dev) for _ in range(3))
+gs = torch.randn(B, T, H, generator=g).to(dev)
+lib = _capi.lib
+lib.sparch_rec_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros((2, 512, 8), np.uint64)
+
+
+def run():
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wx, p["alpha"], p["beta"], p["a"], p["b"], V, u0, w0, s0, None)
+    (s * gs).sum().backward()
+    torch.cuda.synchronize()
+    return s
+
+
+run()
+lib.sparch_rec_prof_read(buf.ctypes.data, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+s = run()
+e1.record()
+torch.cuda.synchronize()
+lib.sparch_rec_prof_read(buf.ctypes.data, 1)
+print(f"fwd+bwd wall {e0.elapsed_time(e1):.3f} ms, firing rate {float(s.mean()):.4f}")
+names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-"],
+         ["flag wait", "loads+mfma+lds", "barrier", "pointwise+stores", "drain vmcnt", "barrier+flag"]]
+for w, label in enumerate(("forward", "backward")):
+    a = buf[w, :256, :6].astype(np.float64) / T
+    print(f"{label}: cycles per step (mean over workgroups | min | max)")
+    for i in range(6):
+        print(f"   {names[w][i]:20s} {a[:, i].mean():9.0f} | {a[:, i].min():9.0f} | {a[:, i].max():9.0f}")
+    print(f"   {'sum':20s} {a.sum(1).mean():9.0f}  (= {a.sum(1).mean() / 100:.2f} us at 100 MHz s_memtime? see note)")
