@@ -72,7 +72,22 @@ int sparch_gemm_nn(int M, int N, int K, const float* A, int lda, const float* B,
  * (sparch_gemm_tn_workspace_bytes), reduced in fixed order => bitwise reproducible.  */
 size_t sparch_gemm_tn_workspace_bytes(int M, int N, int K);
 int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                   float* C, int ldc, int zero_diag, void* ws, size_t ws_bytes, void* stream);
+                   float* C, int ldc, int zero_diag, int accumulate /* C += */, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* The same products when one operand is a spike tensor (entries 0 or one constant c, as produced
+ * by the cell kernels: c = 1/(1-p_drop)): the spike operand is used as (x != 0) in bf16, the fp32
+ * operand is split exactly into three bf16 planes, products are exact on the bf16 MFMA with fp32
+ * accumulation, and `scale` (= c) is applied once in the epilogue.
+ *   spike_nt: C[M,N] = scale * spike(A)[M,K] * B[N,K]^T (+bias) (+BatchNorm column statistics)
+ *   spike_tn: C[M,N] (+)= scale * A[K,M]^T * B[K,N], spike_side 0: A is the spike operand, 1: B. */
+int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int lda, float scale,
+                         const float* B, int ldb, float* C, int ldc, const float* bias,
+                         float* colstat_ws, void* stream);
+size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K);
+int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         int spike_side, float scale, float* C, int ldc, int zero_diag,
+                         int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * G2  normalisation on the (M = B*T, H) view  (replaces nn.BatchNorm1d(momentum=0.05) /

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs g) {
 
 // out[m][n] = sum_z slab[z][m][n] in fixed z order; optional zeroed diagonal
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
-                                     int ldc, int splits, int zero_diag) {
+                                     int ldc, int splits, int zero_diag, int accumulate) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)M * N;
     if (i >= total) return;
@@ -216,7 +216,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += ws[(size_t)z * total + i];
     if (zero_diag && m == n) s = 0.f;
-    C[(size_t)m * ldc + n] = s;
+    float* c = C + (size_t)m * ldc + n;
+    *c = accumulate ? (*c + s) : s;
 }
 
 __global__ void zero_diag_kernel(float* __restrict__ C, int n, int ldc) {
@@ -275,12 +276,12 @@ extern "C" int sparch_gemm_nn(int M, int N, int K, const float* A, int lda, cons
 
 extern "C" size_t sparch_gemm_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int s = choose_splits(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    return (size_t)choose_splits(M, N, K) * M * N * sizeof(float);
 }
 
 extern "C" int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                              float* C, int ldc, int zero_diag, void* ws, size_t ws_bytes, void* stream) {
+                              float* C, int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes,
+                              void* stream) {
     SPARCH_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -290,7 +291,7 @@ extern "C" int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, cons
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
-    if (splits == 1) {
+    if (splits == 1 && !accumulate) {
         g.C = C; g.ldc = ldc; g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0;
         int rc = launch<true, true, EPI_NONE>(g, 1, st);
         if (rc != SPARCH_OK || !zero_diag) return rc;
@@ -307,7 +308,7 @@ extern "C" int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, cons
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const float*)ws, C, M, N, ldc, splits, zero_diag);
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             dwx[e] = valid ? oma[e] * du : 0.0f;
             du_new[e] = du;
             dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
-            spv[e] = sp[e];
+            spv[e] = (t > 0) ? sp[e] : 0.0f;  // binary rows only: the s0 term of dV is added by the host
         }
         // ---- publish dWx_t first: three bf16 planes (write-through), drain, barrier, tag
         if (t > 0) {

@@ -16,6 +16,9 @@ import torch
 from . import _capi
 from ._capi import KIND, check, lib, ptr
 
+# Exact bf16-split MFMA GEMMs for spike operands (SPARCH_SPIKE_GEMM=0 forces the fp32 MFMA everywhere).
+USE_SPIKE_GEMM = os.environ.get("SPARCH_SPIKE_GEMM", "1") != "0"
+
 BN_MOMENTUM = 0.05  # snns.py:240
 NORM_EPS = 1e-5
 
@@ -104,17 +107,23 @@ def _f32c(t):
 
 
 # ----------------------------------------------------------------------------- primitives
-def gemm_nt(A, B, bias=None, colstat=False):
-    """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials."""
+def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None):
+    """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials.
+    spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path."""
     M, K = A.shape
     N = B.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
     ws = None
     if colstat:
         ws = torch.empty(2 * ((M + 127) // 128) * N, dtype=torch.float32, device=A.device)
-    tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
-    check(lib.sparch_gemm_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
-                             ptr(ws), _stream()), "sparch_gemm_nt")
+    if spike_scale is not None and USE_SPIKE_GEMM:
+        tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
+                                       ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
+    else:
+        tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
+                                 ptr(ws), _stream()), "sparch_gemm_nt")
     timer.stop(tok)
     return C, ws
 
@@ -131,16 +140,29 @@ def gemm_nn(A, B):
     return C
 
 
-def gemm_tn(A, B, zero_diag=False):
-    """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis."""
+def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None):
+    """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis.
+    spike_side 0/1: A / B is a spike tensor (entries 0 or spike_scale) -> exact bf16-split MFMA path.
+    out: accumulate into this (M,N) tensor instead of allocating."""
     K, M = A.shape
     N = B.shape[1]
-    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
-    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
-    tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
-    check(lib.sparch_gemm_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, int(zero_diag),
-                             ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
+    accumulate = out is not None
+    C = out if accumulate else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if spike_side is not None and USE_SPIKE_GEMM:
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        tok = timer.start(f"gemm_spike_tn[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_spike_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
+                                       float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
+                                       ptr(ws), nbytes, _stream()), "sparch_gemm_spike_tn")
+    else:
+        if spike_side is not None and spike_scale != 1.0:
+            raise RuntimeError("internal: fp32 gemm_tn fallback expects unscaled operands")
+        nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0),
+                                 int(zero_diag), int(accumulate), ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
     timer.stop(tok)
     return C
 
@@ -305,8 +327,16 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                                       ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
                                       _stream()), "sparch_rec_cell_bwd")
         timer.stop(tok)
-        # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712)
-        grads["V"] = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True)
+        # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
+        # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
+        # (cell step 0 sits at original time 0 for the forward direction, T-1 for the flipped one)
+        dV = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True,
+                     spike_side=0 if USE_SPIKE_GEMM else None)
+        if True:  # s_prev rows of cell step 0 are zero on both paths
+            for dd in range(dirs):
+                rows = slice(dd * B, (dd + 1) * B)
+                gemm_tn(s0[rows], dWx[rows, (T - 1) if dd else 0, :], zero_diag=True, out=dV)
+        grads["V"] = dV
     names = ["alpha"] + (["beta", "a", "b"] if adaptive else [])
     lims = [ALPHA_LIM] + ([BETA_LIM, A_LIM, B_LIM] if adaptive else [])
     outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names], lims)
@@ -330,7 +360,8 @@ class SpikingLayerFn(torch.autograd.Function):
         M = B * T
         x2 = x.view(M, K)
         use_bn_stats = norm == "batchnorm" and training
-        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats)  # snns.py:261
+        in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
@@ -372,7 +403,11 @@ class SpikingLayerFn(torch.autograd.Function):
             dy = dWx
         dy = dy.view(M, H)
         dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
-        dW = gemm_tn(dx_raw, x2)  # (H,K) = dx_raw^T x
+        in_scale = cfg.get("in_spike_scale")
+        if in_scale is not None and USE_SPIKE_GEMM:
+            dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
+        else:
+            dW = gemm_tn(dx_raw, x2)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
         return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),
@@ -394,7 +429,8 @@ class ReadoutLayerFn(torch.autograd.Function):
             raise ValueError("sparch_amd: readout layer supports at most 64 classes")
         M = B * T
         x2 = x.view(M, K)
-        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))  # snns.py:796
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training),
+                                  spike_scale=cfg.get("in_spike_scale"))  # snns.py:796
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, 1)  # 799-801
         out = torch.empty(B, C, dtype=torch.float32, device=x.device)
@@ -424,7 +460,11 @@ class ReadoutLayerFn(torch.autograd.Function):
         (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
         dy = dWx.view(M, C)
         dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
-        dW = gemm_tn(dx_raw, x2)
+        in_scale = cfg.get("in_spike_scale")
+        if in_scale is not None and USE_SPIKE_GEMM:
+            dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)
+        else:
+            dW = gemm_tn(dx_raw, x2)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
         return None, dx, dW, dWb, dnw, dnb, dalpha, None

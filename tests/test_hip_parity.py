@@ -96,6 +96,58 @@ def test_gemm_tn_splitk_deterministic(M, N, K, zd):
     assert torch.equal(C, C2), "split-K reduction must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 70, 700), (257, 35, 1024), (1000, 1024, 96), (64, 129, 44)])
+def test_gemm_spike_nt_exact_split(M, N, K):
+    """A in {0, c}: C = c * (A != 0) @ B^T with B split exactly into three bf16 planes."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(M * 3 + N)
+    c = 1.0 / 0.9
+    A = (torch.rand(M, K, generator=g) < 0.1).float() * c
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().T + bias.double()
+    bound = (A.abs().double() @ B.abs().double().T + bias.abs().double()) * 2e-6 + 1e-6
+    C, ws = Fn.gemm_nt(A.to(DEV), B.to(DEV), bias.to(DEV), colstat=True, spike_scale=c)
+    err = (C.cpu().double() - ref).abs()
+    assert bool((err <= bound).all()), float((err / bound).max())
+    nt = (M + 127) // 128
+    np.testing.assert_allclose(ws.cpu().double().view(2, nt, N)[0].sum(0).numpy(), ref.sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    # dyadic B: every partial sum is exact -> the result must equal the fp64 reference bit for bit
+    Bd = torch.randint(-64, 65, (N, K), generator=g).float() / 128.0
+    A1 = (A != 0).float()
+    C1, _ = Fn.gemm_nt(A1.to(DEV), Bd.to(DEV), spike_scale=1.0)
+    assert torch.equal(C1.cpu().double(), A1.double() @ Bd.double().T)
+
+
+@pytest.mark.parametrize("M,N,K,side,zd", [(128, 700, 3000, 0, False), (96, 96, 5000, 0, True),
+                                           (1024, 260, 2048, 1, False), (35, 1024, 4096, 1, False),
+                                           (700, 35, 1111, 0, False)])
+def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(K + side)
+    c = 1.25
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    if side == 0:
+        A = (torch.rand(K, M, generator=g) < 0.1).float() * c
+    else:
+        B = (torch.rand(K, N, generator=g) < 0.1).float() * c
+    ref = A.double().T @ B.double()
+    if zd:
+        ref.fill_diagonal_(0)
+    bound = (A.abs().double().T @ B.abs().double()) * 2e-6 + 1e-6
+    C = Fn.gemm_tn(A.to(DEV), B.to(DEV), zero_diag=zd, spike_side=side, spike_scale=c)
+    err = (C.cpu().double() - ref).abs()
+    assert bool((err <= bound).all()), float((err / bound).max())
+    C2 = Fn.gemm_tn(A.to(DEV), B.to(DEV), zero_diag=zd, spike_side=side, spike_scale=c)
+    assert torch.equal(C, C2)
+    # accumulate mode of the fp32 TN GEMM (used for the t = 0 term of dV)
+    acc = C.clone()
+    Fn.gemm_tn(A[:64].to(DEV), B[:64].to(DEV), zero_diag=zd, out=acc)
+    ref2 = ref + (lambda r: (r.fill_diagonal_(0) if zd else r))(A[:64].double().T @ B[:64].double())
+    assert bool(((acc.cpu().double() - ref2).abs() <= 2 * bound).all())
+
+
 # ------------------------------------------------------------------------------------ cells
 def _cell_inputs(z, kind):
     p = {k: dev(z[k]).requires_grad_(True) for k in ("alpha", "beta", "a", "b", "V") if k in z}
