@@ -435,6 +435,50 @@ def test_dropout_statistics_and_backward_mask_consistency(sp):
     np.testing.assert_allclose(rate.cpu().numpy(), s_drop.mean(dim=(0, 1)).cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+# ------------------------------------------------------------------------------------ mel front-end
+def test_fbank_vs_numpy_restatement_and_known_answers(sp):
+    """G9.  PARITY UNPINNED against torchaudio (absent, third-party): checked against the independent
+    float64 NumPy restatement in oracle/fbank_numpy.py and analytic known answers."""
+    from oracle import fbank_numpy as fo
+    g = torch.Generator().manual_seed(0)
+    n = 16000
+    t = torch.arange(n) / 16000.0
+    waves = torch.stack([
+        0.1 * (torch.rand(n, generator=g) * 2 - 1) + 0.3 * torch.sin(2 * np.pi * 440.0 * t),   # BASELINE cfg4 shape
+        0.5 * torch.sin(2 * np.pi * 1000.0 * t),                                               # pure tone
+        torch.full((n,), 0.25),                                                                # DC only
+        torch.randn(n, generator=g) * 0.05,
+    ])
+    out = sp.fbank(waves.to(DEV), num_mel_bins=40).cpu().numpy()
+    assert out.shape == (4, 98, 40)
+    for i in (0, 1, 3):
+        ref = fo.fbank(waves[i].numpy())
+        assert np.abs(out[i] - ref).max() <= 2e-3, (i, np.abs(out[i] - ref).max())
+    # known answers: a DC signal has no energy after per-frame DC removal -> log(FLT_EPSILON) floor
+    assert np.allclose(out[2], np.log(np.finfo(np.float32).eps), atol=1e-3)
+    # a 1 kHz tone peaks in the mel bin whose triangle contains 1 kHz
+    centers = 700.0 * (np.exp((fo.mel(20.0) + (np.arange(40) + 1) * (fo.mel(8000.0) - fo.mel(20.0)) / 41) / 1127.0) - 1)
+    assert abs(int(out[1].mean(0).argmax()) - int(np.abs(centers - 1000.0).argmin())) <= 1
+
+
+def test_experiment_cli_synthetic_end_to_end(tmp_path):
+    """run_exp.py plumbing on the GPU: BASELINE configs[0] shape (LIF [128,128,20], B=4, T=100, C=700)
+    on synthetic SHD-shaped spikes, one epoch, checkpoint written, then reload + test-only run."""
+    import run_exp
+    folder = str(tmp_path / "exp_lif")
+    run_exp.main(["--model_type", "LIF", "--nb_layers", "3", "--nb_hiddens", "128", "--dataset_name", "shd",
+                  "--batch_size", "4", "--nb_epochs", "1", "--synthetic", "1", "--synthetic_batches", "3",
+                  "--new_exp_folder", folder, "--use_regularizers", "1"])
+    import os
+    assert os.path.exists(folder + "/checkpoints/best_model.pth")
+    run_exp.main(["--use_pretrained_model", "1", "--only_do_testing", "1", "--load_exp_folder", folder,
+                  "--dataset_name", "shd", "--batch_size", "4", "--synthetic", "1", "--synthetic_batches", "2"])
+    # raw-audio path (sc): waveform -> HIP fbank -> RadLIF
+    run_exp.main(["--model_type", "RadLIF", "--nb_hiddens", "64", "--dataset_name", "sc", "--batch_size", "8",
+                  "--nb_epochs", "1", "--synthetic", "1", "--synthetic_batches", "2", "--save_best", "0",
+                  "--new_exp_folder", str(tmp_path / "exp_sc")])
+
+
 # ------------------------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize("neuron_type,sizes,B,T,C", [("adLIF", [512, 512, 20], 128, 250, 700),
                                                      ("RadLIF", [1024, 1024, 35], 256, 250, 700)])
