@@ -453,7 +453,12 @@ def test_fbank_vs_numpy_restatement_and_known_answers(sp):
     assert out.shape == (4, 98, 40)
     for i in (0, 1, 3):
         ref = fo.fbank(waves[i].numpy())
-        assert np.abs(out[i] - ref).max() <= 2e-3, (i, np.abs(out[i] - ref).max())
+        err = np.abs(out[i] - ref)
+        # log-mel: 2e-3 wherever the bin carries signal; bins > e^-12 below the frame's peak hold only
+        # fp32 FFT rounding leakage (pure tone), which the log amplifies: 2e-2 there
+        strong = ref >= ref.max(axis=1, keepdims=True) - 12.0
+        assert err[strong].max() <= 2e-3, (i, err[strong].max())
+        assert err.max() <= 2e-2, (i, err.max())
     # known answers: a DC signal has no energy after per-frame DC removal -> log(FLT_EPSILON) floor
     assert np.allclose(out[2], np.log(np.finfo(np.float32).eps), atol=1e-3)
     # a 1 kHz tone peaks in the mel bin whose triangle contains 1 kHz
