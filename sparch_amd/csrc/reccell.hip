@@ -16,20 +16,24 @@
 //     V = hi + mid + lo (8+8+8 significand bits, exact).  Spikes are 0/1, exact in bf16, so
 //     s@V = s@hi + s@mid + s@lo runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with
 //     exact products and fp32 accumulation: same accuracy class as an fp32 fmaf chain at 3/16
-//     of its cost.  In the backward dWx is split the same way by its producer and the six
-//     largest cross terms (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are
-//     <= 2^-24 relative) are accumulated: fp32-faithful at 6/16 of the fp32 MFMA cost;
+//     of its cost.  In the backward dWx is split as well (x = t1 + t2 + t3 exactly) and the seven
+//     largest cross terms (t1*hi, t1*mid, t2*hi, t1*lo, t3*hi, t2*mid, t3*mid; the dropped ones
+//     are <= 2^-23 relative) are accumulated: fp32-faithful at 7/16 of the fp32 MFMA cost;
 //   * the 32 workgroups of one batch tile exchange the step's output every step:
 //       forward  — spikes, bit-packed, as 8-byte {tag = t+1, 32 spike bits} granules written
 //                  with one agent-scope (sc1, write-through) store each and polled with sc1
 //                  loads: the data is the flag, no fence (MI355X guide, G16 form R2).  One slot
 //                  per (step, row): never reused inside a call;
-//       backward — the tile of dWx_t as three bf16 planes, 8-byte sc1 stores into a depth-4
-//                  ring, drained (vmcnt(0)) + workgroup barrier, then one sc1 tag store
-//                  (tag = T - t); consumers poll the tag and read the planes with 16-byte sc1
-//                  loads (G16 form R1).  Lock-step makes depth 2 sufficient: a workgroup writes
-//                  step t-1 only after it has read every peer's step t, which they produced
-//                  after reading every step t+1 tile;
+//       backward — the fp32 32x32 tile of dWx_t, stored in MFMA-FRAGMENT ORDER (16-byte piece
+//                  (ks*2+q)*64 + h*32 + row) into a depth-4 ring with 16-byte sc1 (write-through)
+//                  stores, drained (vmcnt(0)) + workgroup barrier, then one sc1 tag store
+//                  (tag = T - t); consumers poll the tag and read the tile with 16-byte sc1 loads
+//                  (G16 form R1) — every wave-load is one contiguous 1 KiB (8 whole lines), where
+//                  reading the natural (B,T,H) layout touched 32 lines for 32 B each — and split
+//                  it into three exact bf16 planes in registers (truncation split: v_perm for the
+//                  high halves, AND + SUB for the residuals).  Lock-step makes ring depth 2
+//                  sufficient: a workgroup writes step t-1 only after it has read every peer's
+//                  step t, which they produced after reading every step t+1 tile;
 //   * block -> tile mapping keeps a batch tile's workgroups at equal blockIdx % n_row_tiles,
 //     i.e. on one XCD under round-robin dispatch.  That is a speed choice only: every
 //     hand-off is agent-scope and placement-independent.  Every spin is bounded by a
@@ -52,6 +56,7 @@ constexpr int RT = 32;       // rows per batch tile
 constexpr int CT = 32;       // columns per workgroup (= one k-group of its consumers)
 constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
 constexpr int RING = 4;      // depth of the backward hand-off ring (2 suffices, see header)
+constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 constexpr u64 TIMEOUT_TICKS = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
 struct RecArgs {
@@ -69,7 +74,7 @@ struct RecArgs {
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; float* s_prev; float* dparam_ws;
     // hand-off
-    u64* chan; unsigned* flags; unsigned short* planes; unsigned* status;
+    u64* chan; unsigned* flags; char* ring; unsigned* status;
 };
 
 // Diagnostic build only (-DSPARCH_REC_PROF, never shipped): per-workgroup sums of s_memtime
@@ -355,7 +360,7 @@ template <bool ADAPT, int KGW>
 __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][4][RT * RED_LD];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
-    // hi/mid planes (128 VGPRs) plus all 48 in-flight dWx plane fragments (192 VGPRs) without spilling
+    // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
     __shared__ __attribute__((aligned(16))) u32x4 vlo[4][KGW][2][64];
     __shared__ int abort_flag[2];
 
@@ -366,7 +371,6 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     const int rt = a.rt_base + (int)(blockIdx.x % a.n_rt_launch);
     const int ct = (int)(blockIdx.x / a.n_rt_launch);
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
-    const int Hp = a.n_ct * CT;  // padded row length of the hand-off planes
 
     const int r = tid >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
@@ -420,12 +424,10 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     if (tid < 2) abort_flag[tid] = 0;
     __syncthreads();
 
-    // hand-off ring: planes[slot][rt][p][row][Hp] bf16, one buffer resource for the whole ring
-    const size_t slot_elems = (size_t)a.n_rt_total * 3 * RT * Hp;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.planes, 0, (int)(RING * slot_elems * sizeof(unsigned short)), 0x00020000);
-    const unsigned tile_off = (unsigned)(((size_t)rt * 3 * RT) * Hp * sizeof(unsigned short));  // bytes, plane 0 row 0
-    const unsigned plane_bytes = (unsigned)((size_t)RT * Hp * sizeof(unsigned short));
+    // hand-off ring: ring[slot][rt][ct] = one 4 KiB fp32 tile in fragment order; one buffer resource
+    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * TILE_BYTES);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
+    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
 
     const bool drop = a.p_drop > 0.0f;
     auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp) {
@@ -451,8 +453,8 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         const int par = t & 1;
 
         if (t + 1 < T) {
-            // ---- wait for the dWx_{t+1} tiles of this wave's producers (tag T-(t+1)), then read
-            //      their bf16 planes (sc1): all loads in flight before the first MFMA
+            // ---- wait for the dWx_{t+1} tiles of this wave's producers, then read them (sc1): all
+            //      loads in flight before the first MFMA
             const unsigned slot = (unsigned)((t + 1) % RING);
             const unsigned want = (unsigned)(T - (t + 1));
             const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
@@ -474,21 +476,22 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_STAMP(0);  // flag wait
-            const unsigned base = (unsigned)(slot * slot_elems * sizeof(unsigned short)) + tile_off +
-                                  (unsigned)(((size_t)li * Hp + 8 * hh) * sizeof(unsigned short));
-            u32x4 af[KGW][2][3];
+            // lane (row li, k-half hh) of k16-step ks needs k = 16*ks + 8*hh + 4q + 0..3 of producer tile kg:
+            // piece (ks*2+q)*64 + lane of that tile -> each wave-load is 1 KiB contiguous
+            const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
+            u32x4 raw[KGW][2][2];
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
                 const int kg = wave + 4 * kk;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int q = 0; q < 2; ++q) {
                         if (kg < a.n_ct) {
-                            const unsigned off = base + p * plane_bytes + (unsigned)((kg * 32 + 16 * ks) * 2);
-                            af[kk][ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
+                            const unsigned off = base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024);
+                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
                         } else {
-                            af[kk][ks][p] = u32x4{0u, 0u, 0u, 0u};
+                            raw[kk][ks][q] = u32x4{0u, 0u, 0u, 0u};
                         }
                     }
             }
@@ -501,13 +504,31 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 if (kg < a.n_ct) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        // six largest cross terms of (g_hi+g_mid+g_lo)(V_hi+V_mid+V_lo), small first
-                        acc = mfma_bf16(af[kk][ks][1], vb[kk][ks][1], acc);  // mid*mid
-                        acc = mfma_bf16(af[kk][ks][2], vb[kk][ks][0], acc);  // lo *hi
-                        acc = mfma_bf16(af[kk][ks][0], vlo[wave][kk][ks][lane], acc);  // hi *lo
-                        acc = mfma_bf16(af[kk][ks][1], vb[kk][ks][0], acc);  // mid*hi
-                        acc = mfma_bf16(af[kk][ks][0], vb[kk][ks][1], acc);  // hi *mid
-                        acc = mfma_bf16(af[kk][ks][0], vb[kk][ks][0], acc);  // hi *hi
+                        // exact truncation split of the 8 fp32 values into three bf16 fragments
+                        u32x4 p1, p2, p3;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {
+                                const unsigned x0 = raw[kk][ks][q][2 * pr], x1 = raw[kk][ks][q][2 * pr + 1];
+                                const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
+                                const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
+                                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                                p1[2 * q + pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                                p2[2 * q + pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                                p3[2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                            }
+                        const u32x4 vl = vlo[wave][kk][ks][lane];
+                        // seven largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first
+                        acc = mfma_bf16(p3, vb[kk][ks][1], acc);  // t3*mid
+                        acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
+                        acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
+                        acc = mfma_bf16(p1, vl, acc);             // t1*lo
+                        acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
+                        acc = mfma_bf16(p1, vb[kk][ks][1], acc);  // t1*mid
+                        acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
                     }
                 }
             }
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 rd[row * RED_LD + li] = acc[i];
             }
-            PROF_STAMP(1);  // plane loads + MFMA + LDS write
+            PROF_STAMP(1);  // tile loads + split + MFMA + LDS write
         }
         __syncthreads();
         PROF_STAMP(2);  // barrier
@@ -559,23 +580,18 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
             spv[e] = (t > 0) ? sp[e] : 0.0f;  // binary rows only: the s0 term of dV is added by the host
         }
-        // ---- publish dWx_t first: three bf16 planes (write-through), drain, barrier, tag
+        // ---- publish dWx_t first: this thread's 4 values are one 16-byte piece of the tile in fragment
+        //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1);
+        //      write-through, drain, barrier, tag
         if (t > 0) {
-            u32x2 pk[3];
-            unsigned short h0[4], m0[4], l0[4];
+            const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
+            const unsigned off = (unsigned)(t % RING) * slot_bytes + rt_off + (unsigned)ct * TILE_BYTES + piece;
+            u32x4 rawv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split3(dwx[e], h0[e], m0[e], l0[e]);
-            pk[0] = u32x2{(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
-            pk[1] = u32x2{(unsigned)m0[0] | ((unsigned)m0[1] << 16), (unsigned)m0[2] | ((unsigned)m0[3] << 16)};
-            pk[2] = u32x2{(unsigned)l0[0] | ((unsigned)l0[1] << 16), (unsigned)l0[2] | ((unsigned)l0[3] << 16)};
-            const unsigned slot = (unsigned)(t % RING);
-            const unsigned off = (unsigned)(slot * slot_elems * sizeof(unsigned short)) + tile_off +
-                                 (unsigned)(((size_t)r * Hp + ct * CT + cq * 4) * sizeof(unsigned short));
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                __builtin_amdgcn_raw_buffer_store_b64(pk[p], rsrc, off + p * plane_bytes, 0, 16 /* sc1 */);
+            for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
+            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, 16 /* sc1 */);
         }
-        PROF_STAMP(3);  // pointwise + plane stores issue
+        PROF_STAMP(3);  // pointwise + tile store issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PROF_STAMP(4);  // drain
         __syncthreads();
@@ -671,8 +687,8 @@ size_t bwd_flag_bytes(int Bp, int H) {
     const size_t b = (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * sizeof(unsigned);
     return (b + 255) / 256 * 256;
 }
-size_t bwd_plane_bytes(int Bp, int H) {
-    return (size_t)RING * cdiv(Bp, RT) * 3 * RT * (cdiv(H, CT) * CT) * sizeof(unsigned short);
+size_t bwd_ring_bytes(int Bp, int H) {
+    return (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * TILE_BYTES;
 }
 
 template <bool BWD, bool ADAPT>
@@ -707,7 +723,7 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
         const size_t fb = bwd_flag_bytes(a.Bp, a.H);
         if (hipMemsetAsync(a.chan, 0, fb, st) != hipSuccess) return SPARCH_ELAUNCH;
         a.flags = reinterpret_cast<unsigned*>(a.chan);
-        a.planes = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.chan) + fb);
+        a.ring = reinterpret_cast<char*>(a.chan) + fb;
     }
 
     int L = steps_per_launch;
@@ -787,8 +803,8 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
 
 extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
-    // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: tags + bf16 plane ring
-    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_flag_bytes(Bp, H) + bwd_plane_bytes(Bp, H);
+    // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: tags + fp32 tile ring
+    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_flag_bytes(Bp, H) + bwd_ring_bytes(Bp, H);
     return f > b ? f : b;
 }
 
@@ -837,7 +853,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
     if (!al16({g_out, u_save, w_save, vpack_t, u0, w0, s0, dWx, s_prev, dparam_ws, chan})) return SPARCH_EALIGN;
-    if (bwd_plane_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
+    if (bwd_ring_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
     RecArgs r{};
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
