@@ -147,12 +147,17 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool A_KM, bool B_KM, bool SPIKE_A, int EPI>
+// MODE 0: A is the spike operand; MODE 1: B is; MODE 2: both operands are dense fp32 and both are split
+// (six cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative).
+template <bool A_KM, bool B_KM, int MODE, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
-    // one array (guide: keep all LDS in one object): spike operand 1 plane + split operand 3 planes
-    __shared__ __attribute__((aligned(16))) unsigned short lds[4 * PLANE];
+    constexpr bool SPIKE_A = MODE == 0;
+    constexpr bool SPIKE_B = MODE == 1;
+    constexpr int A_PLANES = SPIKE_A ? 1 : 3, B_PLANES = SPIKE_B ? 1 : 3;
+    // one array (guide: keep all LDS in one object)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(A_PLANES + B_PLANES) * PLANE];
     unsigned short* As = lds;
-    unsigned short* Bs = lds + (SPIKE_A ? 1 : 3) * PLANE;
+    unsigned short* Bs = lds + A_PLANES * PLANE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
 
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         stage_store<A_KM, SPIKE_A>(ra, As, tid);
-        stage_store<B_KM, !SPIKE_A>(rb, Bs, tid);
+        stage_store<B_KM, SPIKE_B>(rb, Bs, tid);
         __syncthreads();
         if (k0 + BK < k_end) {
             stage_load<A_KM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
@@ -186,7 +191,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if constexpr (SPIKE_A) {
+            if constexpr (MODE == 2) {
+                u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fa[i][p] = frag_read<A_KM>(As + p * PLANE, wm * 64 + i * 32, lane, ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fb[j][p] = frag_read<B_KM>(Bs + p * PLANE, wn * 64 + j * 32, lane, ks);
+                // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+                constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i][PA[c]], fb[j][PB[c]], acc[i][j]);
+            } else if constexpr (SPIKE_A) {
                 u32x4 fa[2], fb[2][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = frag_read<A_KM>(As, wm * 64 + i * 32, lane, ks);
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
         }
     }
     if constexpr (EPI & EPI_STATS) {
-        float* red = reinterpret_cast<float*>(lds);  // [2 (sum|sq)][2 (wm)][128]
+        float* red = reinterpret_cast<float*>(lds);  // [2 (sum|sq)][2 (wm)][128] (2 KiB <= any LDS size here)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             csum[j] += __shfl_xor(csum[j], 32);
@@ -286,10 +310,10 @@ int choose_splits(int M, int N, int K) {
     return s;
 }
 
-template <bool A_KM, bool B_KM, bool SPIKE_A, int EPI>
+template <bool A_KM, bool B_KM, int MODE, int EPI>
 int launch(SArgs& g, int splits, hipStream_t st) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-    hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, SPIKE_A, EPI>), dim3(tiles, splits, 1), dim3(NT), 0, st, g);
+    hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI>), dim3(tiles, splits, 1), dim3(NT), 0, st, g);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
@@ -308,9 +332,9 @@ extern "C" int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int
     g.a_vec = aligned16(A_spk) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (colstat_ws) return launch<false, false, true, EPI_BIAS | EPI_STATS>(g, 1, st);
-    if (bias) return launch<false, false, true, EPI_BIAS>(g, 1, st);
-    return launch<false, false, true, EPI_NONE>(g, 1, st);
+    if (colstat_ws) return launch<false, false, 0, EPI_BIAS | EPI_STATS>(g, 1, st);
+    if (bias) return launch<false, false, 0, EPI_BIAS>(g, 1, st);
+    return launch<false, false, 0, EPI_NONE>(g, 1, st);
 }
 
 extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -329,8 +353,61 @@ extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
     g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
-    int rc = spike_side == 0 ? launch<true, true, true, EPI_NONE>(g, splits, st)
-                             : launch<true, true, false, EPI_NONE>(g, splits, st);
+    int rc = spike_side == 0 ? launch<true, true, 0, EPI_NONE>(g, splits, st)
+                             : launch<true, true, 1, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+// ---- dense x dense on the exact 6-term split (same signatures as the fp32-MFMA entry points in gemm.hip)
+extern "C" int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                               int ldc, const float* bias, float* colstat_ws, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (colstat_ws) return launch<false, false, 2, EPI_BIAS | EPI_STATS>(g, 1, st);
+    if (bias) return launch<false, false, 2, EPI_BIAS>(g, 1, st);
+    return launch<false, false, 2, EPI_NONE>(g, 1, st);
+}
+
+extern "C" int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                               int ldc, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    return launch<false, true, 2, EPI_NONE>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                               int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = choose_splits(M, N, K);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
+    SArgs g{};
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    int rc = launch<true, true, 2, EPI_NONE>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

@@ -19,6 +19,9 @@ from ._capi import KIND, check, lib, ptr
 # Exact bf16-split MFMA GEMMs for spike operands (SPARCH_SPIKE_GEMM=0 forces the fp32 MFMA everywhere).
 USE_SPIKE_GEMM = os.environ.get("SPARCH_SPIKE_GEMM", "1") != "0"
 
+# Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
+DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
+
 BN_MOMENTUM = 0.05  # snns.py:240
 NORM_EPS = 1e-5
 
@@ -121,9 +124,10 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None):
         check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
                                        ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
     else:
+        fn = lib.sparch_gemm6_nt if DENSE_GEMM == "split6" else lib.sparch_gemm_nt
         tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
-        check(lib.sparch_gemm_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
-                                 ptr(ws), _stream()), "sparch_gemm_nt")
+        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream()),
+              "sparch_gemm_nt")
     timer.stop(tok)
     return C, ws
 
@@ -133,9 +137,9 @@ def gemm_nn(A, B):
     M, K = A.shape
     N = B.shape[1]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    fn = lib.sparch_gemm6_nn if DENSE_GEMM == "split6" else lib.sparch_gemm_nn
     tok = timer.start(f"gemm_nn[{M}x{N}x{K}]")
-    check(lib.sparch_gemm_nn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()),
-          "sparch_gemm_nn")
+    check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()), "sparch_gemm_nn")
     timer.stop(tok)
     return C
 
@@ -160,9 +164,10 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None):
             raise RuntimeError("internal: fp32 gemm_tn fallback expects unscaled operands")
         nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        fn = lib.sparch_gemm6_tn if DENSE_GEMM == "split6" else lib.sparch_gemm_tn
         tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
-        check(lib.sparch_gemm_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0),
-                                 int(zero_diag), int(accumulate), ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
+        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(zero_diag),
+                 int(accumulate), ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
     timer.stop(tok)
     return C
 

@@ -45,8 +45,15 @@ def relmax(a, b):
 
 
 # ------------------------------------------------------------------------------------ GEMM
+@pytest.fixture(params=["split6", "fp32"])
+def dense_impl(request, monkeypatch):
+    """Both dense GEMM implementations: exact 6-term bf16 split (default) and the fp32-input MFMA."""
+    monkeypatch.setattr(_Fn(), "DENSE_GEMM", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 70, 700), (257, 35, 1024), (128, 128, 32), (1000, 129, 41), (64, 1024, 700)])
-def test_gemm_nt_bias_and_colstats(M, N, K):
+def test_gemm_nt_bias_and_colstats(M, N, K, dense_impl):
     Fn = _Fn()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -67,7 +74,7 @@ def test_gemm_nt_bias_and_colstats(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 700, 128), (257, 1024, 35), (64, 44, 1000)])
-def test_gemm_nn(M, N, K):
+def test_gemm_nn(M, N, K, dense_impl):
     Fn = _Fn()
     g = torch.Generator().manual_seed(7 + M)
     A = torch.randn(M, K, generator=g)
@@ -80,7 +87,7 @@ def test_gemm_nn(M, N, K):
 
 @pytest.mark.parametrize("M,N,K,zd", [(128, 700, 3000, False), (96, 96, 5000, True), (35, 1024, 2048, False),
                                       (1024, 1024, 4096, True)])
-def test_gemm_tn_splitk_deterministic(M, N, K, zd):
+def test_gemm_tn_splitk_deterministic(M, N, K, zd, dense_impl):
     Fn = _Fn()
     g = torch.Generator().manual_seed(11 + K)
     A = torch.randn(K, M, generator=g)
