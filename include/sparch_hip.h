@@ -97,6 +97,20 @@ int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, const float* B
 int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
+
+/* First-layer input (snns.py:261 on the network input): SHD/SSC-style binned spike counts are small
+ * integers, exactly representable in bf16, but the library cannot know that on the host.
+ * sparch_flag_bf16_exact sets *flag (device uint32) to 1 iff every element of x is bf16-exact; the
+ * _auto_ GEMMs then enqueue BOTH the single-plane exact kernel and the 6-term kernel, each gated on
+ * the device by *flag, so exactly one runs — no host round trip.  nt: A is the flagged operand;
+ * tn: B is (dW = dWx^T x).                                                                       */
+int sparch_flag_bf16_exact(size_t n, const float* x, uint32_t* flag, void* stream);
+int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, const float* bias, float* colstat_ws,
+                        const uint32_t* a_exact_flag, void* stream);
+int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, int zero_diag, int accumulate,
+                        const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream);
 int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          int spike_side, float scale, float* C, int ldc, int zero_diag,
                          int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -42,6 +42,10 @@ PROTOTYPES = {
     "sparch_gemm6_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm6_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
     "sparch_gemm6_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "sparch_flag_bf16_exact": (c_int, [c_size_t, P, P, P]),
+    "sparch_gemm_auto_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),
+    "sparch_gemm_auto_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P,
+                                    c_size_t, P]),
     "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
                                    P, P, P, P, P]),
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

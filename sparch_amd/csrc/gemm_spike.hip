@@ -41,6 +41,11 @@ struct SArgs {
     int k_per_split; size_t c_split_stride;
     int a_vec, b_vec;
     float scale;
+    // device-side gate: the whole launch returns at once unless *gate == gate_want (lets the host enqueue
+    // both the exact single-plane kernel and the 6-term kernel for an operand whose bf16-exactness is
+    // only known on the device, with no host round trip)
+    const unsigned* gate; unsigned gate_want;
+    int e_exact;  // spike operand conversion: 0 = (x != 0), 1 = x itself (caller guarantees bf16-exact values)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -96,7 +101,8 @@ __device__ __forceinline__ void stage_load(f32x4 (&r)[4], const float* __restric
 
 // ---- registers -> LDS with conversion.  SPIKE: one plane of 0/1; else three planes hi/mid/lo.
 template <bool KM, bool SPIKE>
-__device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short* __restrict__ S, int tid) {
+__device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short* __restrict__ S, int tid,
+                                            int e_exact = 0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int f = tid + NT * p;
@@ -105,8 +111,13 @@ __device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short*
         else               off = (f >> 5) * KM_ROW + ((f & 31) << 2);
         if constexpr (SPIKE) {
             u32x2 w;
-            w.x = (r[p].x != 0.f ? 0x3F80u : 0u) | (r[p].y != 0.f ? 0x3F800000u : 0u);
-            w.y = (r[p].z != 0.f ? 0x3F80u : 0u) | (r[p].w != 0.f ? 0x3F800000u : 0u);
+            if (e_exact) {  // values are bf16-exact: their bf16 form is the upper half of the fp32 word
+                w.x = __builtin_amdgcn_perm(__float_as_uint(r[p].y), __float_as_uint(r[p].x), 0x07060302u);
+                w.y = __builtin_amdgcn_perm(__float_as_uint(r[p].w), __float_as_uint(r[p].z), 0x07060302u);
+            } else {
+                w.x = (r[p].x != 0.f ? 0x3F80u : 0u) | (r[p].y != 0.f ? 0x3F800000u : 0u);
+                w.y = (r[p].z != 0.f ? 0x3F80u : 0u) | (r[p].w != 0.f ? 0x3F800000u : 0u);
+            }
             *reinterpret_cast<u32x2*>(S + off) = w;
         } else {
             unsigned short h[4], m[4], l[4];
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
     unsigned short* As = lds;
     unsigned short* Bs = lds + A_PLANES * PLANE;
 
+    if (g.gate != nullptr && *g.gate != g.gate_want) return;  // uniform: every workgroup reads the same word
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
     stage_load<B_KM>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
 
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        stage_store<A_KM, SPIKE_A>(ra, As, tid);
-        stage_store<B_KM, SPIKE_B>(rb, Bs, tid);
+        stage_store<A_KM, SPIKE_A>(ra, As, tid, g.e_exact);
+        stage_store<B_KM, SPIKE_B>(rb, Bs, tid, g.e_exact);
         __syncthreads();
         if (k0 + BK < k_end) {
             stage_load<A_KM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
@@ -408,6 +420,87 @@ extern "C" int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, con
     g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
     g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
     int rc = launch<true, true, 2, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+// ---- operand whose exactness in bf16 is known only on the device
+__global__ void flag_bf16_exact_kernel(size_t n4, const u32x4* __restrict__ x, unsigned* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bad = 0;
+    for (size_t j = i; j < n4; j += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 v = x[j];
+        bad |= (v.x | v.y | v.z | v.w) & 0xFFFFu;
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0u);
+}
+__global__ void flag_set_kernel(unsigned* flag, unsigned v) { *flag = v; }
+
+extern "C" int sparch_flag_bf16_exact(size_t n, const float* x, uint32_t* flag, void* stream) {
+    SPARCH_ENTER();
+    if (n == 0 || !x || !flag) return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = aligned16(x) && (n % 4 == 0);
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, st, flag, vec ? 1u : 0u);
+    SPARCH_CHECK_LAUNCH();
+    if (vec) {
+        hipLaunchKernelGGL(flag_bf16_exact_kernel, dim3(2048), dim3(256), 0, st, n / 4,
+                           reinterpret_cast<const u32x4*>(x), flag);
+        SPARCH_CHECK_LAUNCH();
+    }
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                   float* C, int ldc, const float* bias, float* colstat_ws,
+                                   const uint32_t* a_exact_flag, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N || !a_exact_flag)
+        return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    g.gate = a_exact_flag; g.e_exact = 1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    g.gate_want = 1;  // A is bf16-exact: single plane for A, three for B
+    if (colstat_ws) rc = launch<false, false, 0, EPI_BIAS | EPI_STATS>(g, 1, st);
+    else rc = launch<false, false, 0, EPI_BIAS>(g, 1, st);
+    if (rc != SPARCH_OK) return rc;
+    g.gate_want = 0;  // otherwise: both operands split, six cross terms
+    if (colstat_ws) return launch<false, false, 2, EPI_BIAS | EPI_STATS>(g, 1, st);
+    return launch<false, false, 2, EPI_BIAS>(g, 1, st);
+}
+
+extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                   float* C, int ldc, int zero_diag, int accumulate,
+                                   const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N || !b_exact_flag)
+        return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = choose_splits(M, N, K);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
+    SArgs g{};
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    g.gate = b_exact_flag; g.e_exact = 1;
+    g.gate_want = 1;
+    int rc = launch<true, true, 1, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    g.gate_want = 0;
+    rc = launch<true, true, 2, EPI_NONE>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

@@ -14,18 +14,21 @@ namespace {
 
 constexpr int RB = 256;  // rows per partial block in column reductions
 
-// Sum rows [0,n) of a row-major [n][ld] fp32 array for 64 adjacent columns per 256-thread block:
-// thread (c = tid&63, q = tid>>6) adds rows q, q+4, ... in fp64 (coalesced 256-B row segments),
-// the four row-lanes meet in LDS in a fixed order.  Returns the total to the q == 0 threads.
+// Sum rows [0,n) of a row-major [n][ld] fp32 array for 16 adjacent columns per 256-thread block:
+// thread (c = tid&15, q = tid>>4) adds rows q, q+16, ... in fp64 (64-B row segments), the sixteen
+// row-lanes meet in LDS in a fixed order.  Returns the total to the q == 0 threads (tid < 16).
+constexpr int CS_COLS = 16, CS_LANES = 16;
 __device__ __forceinline__ double col_sum64(const float* __restrict__ base, int n, size_t ld, int col, bool ok,
-                                            double (*red)[64]) {
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+                                            double (*red)[CS_COLS]) {
+    const int c = threadIdx.x & (CS_COLS - 1), q = threadIdx.x / CS_COLS;
     double s = 0.0;
     if (ok)
-        for (int r = q; r < n; r += 4) s += (double)base[(size_t)r * ld + col];
+        for (int r = q; r < n; r += CS_LANES) s += (double)base[(size_t)r * ld + col];
     red[q][c] = s;
     __syncthreads();
-    const double tot = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < CS_LANES; ++i) tot += red[i][c];
     __syncthreads();
     return tot;
 }
@@ -37,15 +40,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_ti
                                    float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-    __shared__ double red[4][64];
-    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double red[CS_LANES][CS_COLS];
+    const int h = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1));
     const bool ok = h < H;
     double s = 0.0, ss = 0.0;
     if (training) {
         s = col_sum64(ws, n_tiles, H, h, ok, red);
         ss = col_sum64(ws + (size_t)n_tiles * H, n_tiles, H, h, ok, red);
     }
-    if (!ok || threadIdx.x >= 64) return;
+    if (!ok || threadIdx.x >= CS_COLS) return;
     float mean, var;
     if (training) {
         const double mu = s / (double)M;
@@ -130,36 +133,49 @@ __global__ __launch_bounds__(256) void colpartial_kernel(int M, int H, const flo
 
 __global__ __launch_bounds__(256) void colfinish_kernel(int H, int n_rb, int n_out, const float* __restrict__ ws,
                                                         float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ double red[4][64];
-    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double red[CS_LANES][CS_COLS];
+    const int h = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1));
     const bool ok = h < H;
     const double s0 = col_sum64(ws, n_rb, H, h, ok, red);
     double s1 = 0.0;
     if (n_out > 1) s1 = col_sum64(ws + (size_t)n_rb * H, n_rb, H, h, ok, red);
-    if (!ok || threadIdx.x >= 64) return;
+    if (!ok || threadIdx.x >= CS_COLS) return;
     out0[h] = (float)s0;
     if (n_out > 1) out1[h] = (float)s1;
 }
 
-// dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M)
-__global__ void bn_bwd_apply_kernel(size_t n4, int H, float invM, const float* __restrict__ dy,
-                                    const float* __restrict__ x, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    float* __restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % (size_t)H);
-    const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-    f32x4 o;
+// dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M) = k1*dy + k2*x + k3 with per-column k1,k2,k3:
+// a thread keeps the coefficients of its 4 columns in registers and strides over rows.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int H, float invM, const float* __restrict__ dy,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta,
+                                                           float* __restrict__ dx) {
+    const int HQ = H / 4;
+    const int cq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cq >= HQ) return;
+    const int c = cq * 4;
+    f32x4 k1, k2, k3;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float is = invstd[c + e];
-        const float xh = (xv[e] - mean[c + e]) * is;
-        o[e] = gamma[c + e] * is * (d[e] - dbeta[c + e] * invM - xh * (dgamma[c + e] * invM));
+        const float is = invstd[c + e], gi = gamma[c + e] * is;
+        const float t = is * (dgamma[c + e] * invM);
+        k1[e] = gi;
+        k2[e] = -(gi * t);
+        k3[e] = gi * (mean[c + e] * t - dbeta[c + e] * invM);
     }
-    reinterpret_cast<f32x4*>(dx)[i] = o;
+    for (int r = blockIdx.y; r < M; r += gridDim.y) {
+        const size_t o = (size_t)r * H + c;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = k1[e] * d[e] + k2[e] * xv[e] + k3[e];
+        *reinterpret_cast<f32x4*>(dx + o) = out;
+    }
 }
 
 __global__ void bn_bwd_apply_scalar_kernel(size_t n, int H, float invM, const float* __restrict__ dy,
@@ -246,12 +262,12 @@ struct ClampArgs {
 };
 __global__ __launch_bounds__(256) void colsum_clamped_kernel(int n_params, int rows, int H,
                                                              const float* __restrict__ ws, ClampArgs a) {
-    __shared__ double red[4][64];
-    const int h = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double red[CS_LANES][CS_COLS];
+    const int h = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1));
     const int j = blockIdx.y;
     const bool ok = h < H;
     const double s = col_sum64(ws + (size_t)j * rows * H, rows, H, h, ok, red);
-    if (!ok || threadIdx.x >= 64) return;
+    if (!ok || threadIdx.x >= CS_COLS) return;
     float v = (float)s;
     if (a.gated[j]) {
         const float x = a.raw[j][h];
@@ -270,7 +286,7 @@ extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const floa
     SPARCH_ENTER();
     if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
     if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, 64)), dim3(256), 0, (hipStream_t)stream, H, M,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, (hipStream_t)stream, H, M,
                        n_tiles, dup, colstat_ws, gamma, beta, running_mean, running_var, momentum, eps,
                        training, scale, shift, save_mean, save_invstd);
     SPARCH_CHECK_LAUNCH();
@@ -294,7 +310,7 @@ extern "C" int sparch_bn_bwd_reduce(int M, int H, const float* dy, const float* 
     hipLaunchKernelGGL(colpartial_kernel<1>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mean,
                        invstd, (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
                        dbeta, dgamma);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -309,9 +325,10 @@ extern "C" int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x
     const size_t n = (size_t)M * H;
     hipStream_t st = (hipStream_t)stream;
     if (H % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(dx)) {
-        const size_t n4 = n / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, H,
-                           1.0f / (float)M, dy, x, mean, invstd, gamma, dgamma, dbeta, dx);
+        const int bx = cdiv(H / 4, 256);
+        const int by = M < 4096 / bx ? M : 4096 / bx;  // ~4096 workgroups stride over the rows
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx, by), dim3(256), 0, st, M, H, 1.0f / (float)M, dy, x,
+                           mean, invstd, gamma, dgamma, dbeta, dx);
     } else {
         hipLaunchKernelGGL(bn_bwd_apply_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
                            H, 1.0f / (float)M, dy, x, mean, invstd, gamma, dgamma, dbeta, dx);
@@ -343,7 +360,7 @@ extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* 
     hipLaunchKernelGGL(colpartial_kernel<2>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mu, rstd,
                        (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
                        dbeta, dgamma);
     SPARCH_CHECK_LAUNCH();
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, M, H, dy, x, mu, rstd, gamma,
@@ -363,7 +380,7 @@ extern "C" int sparch_colsum(int M, int H, const float* x, float* out, void* ws,
     hipLaunchKernelGGL(colpartial_kernel<0>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, x, x,
                        (const float*)nullptr, (const float*)nullptr, (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, st, H, n_rb, 1, (const float*)ws, out,
+    hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, st, H, n_rb, 1, (const float*)ws, out,
                        (float*)nullptr);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -391,7 +408,7 @@ extern "C" int sparch_colsum_clamped(int n_params, int rows, int H, const float*
         a.gated[j] = (raw && raw[j] && lim_lo_hi) ? 1 : 0;
         if (a.gated[j]) { a.lo[j] = lim_lo_hi[2 * j]; a.hi[j] = lim_lo_hi[2 * j + 1]; }
     }
-    hipLaunchKernelGGL(colsum_clamped_kernel, dim3(cdiv(H, 64), n_params), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_clamped_kernel, dim3(cdiv(H, CS_COLS), n_params), dim3(256), 0, (hipStream_t)stream,
                        n_params, rows, H, ws, a);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;

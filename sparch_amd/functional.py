@@ -110,7 +110,14 @@ def _f32c(t):
 
 
 # ----------------------------------------------------------------------------- primitives
-def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None):
+def flag_bf16_exact(x):
+    """Device uint32: 1 iff every element of x is exactly representable in bf16 (no host sync)."""
+    flag = torch.empty(4, dtype=torch.int32, device=x.device)
+    check(lib.sparch_flag_bf16_exact(x.numel(), ptr(x), ptr(flag), _stream()), "sparch_flag_bf16_exact")
+    return flag
+
+
+def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None):
     """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials.
     spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path."""
     M, K = A.shape
@@ -123,6 +130,10 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None):
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
                                        ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
+    elif a_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
+        tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_auto_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
+                                      ptr(ws), ptr(a_exact_flag), _stream()), "sparch_gemm_auto_nt")
     else:
         fn = lib.sparch_gemm6_nt if DENSE_GEMM == "split6" else lib.sparch_gemm_nt
         tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
@@ -144,7 +155,7 @@ def gemm_nn(A, B):
     return C
 
 
-def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None):
+def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b_exact_flag=None):
     """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis.
     spike_side 0/1: A / B is a spike tensor (entries 0 or spike_scale) -> exact bf16-split MFMA path.
     out: accumulate into this (M,N) tensor instead of allocating."""
@@ -159,6 +170,13 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None):
         check(lib.sparch_gemm_spike_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
                                        float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
                                        ptr(ws), nbytes, _stream()), "sparch_gemm_spike_tn")
+    elif b_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_auto_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0),
+                                      int(zero_diag), int(accumulate), ptr(b_exact_flag), ptr(ws), nbytes,
+                                      _stream()), "sparch_gemm_auto_tn")
     else:
         if spike_side is not None and spike_scale != 1.0:
             raise RuntimeError("internal: fp32 gemm_tn fallback expects unscaled operands")
@@ -366,7 +384,11 @@ class SpikingLayerFn(torch.autograd.Function):
         x2 = x.view(M, K)
         use_bn_stats = norm == "batchnorm" and training
         in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
-        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale)  # snns.py:261
+        # otherwise (network input): let the device decide whether x is bf16-exact (binned spike counts are)
+        xflag = flag_bf16_exact(x2) if (in_scale is None and USE_SPIKE_GEMM) else None
+        ctx.xflag = xflag
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale,
+                                  a_exact_flag=xflag)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
@@ -412,7 +434,7 @@ class SpikingLayerFn(torch.autograd.Function):
         if in_scale is not None and USE_SPIKE_GEMM:
             dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
         else:
-            dW = gemm_tn(dx_raw, x2)
+            dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
         return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),

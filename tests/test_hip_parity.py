@@ -155,6 +155,33 @@ def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
     assert bool(((acc.cpu().double() - ref2).abs() <= 2 * bound).all())
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_gemm_auto_device_gated_paths(exact):
+    """Network-input GEMMs: the bf16-exactness flag is computed on the device and gates which of the two
+    enqueued kernels runs.  Integer spike counts take the single-plane path, real-valued input the 6-term one;
+    both must meet the fp32 GEMM bound, and the flag must be right."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 1000, 260, 700
+    if exact:
+        A = torch.poisson(torch.full((M, K), 0.2), generator=g)   # counts 0,1,2,...
+    else:
+        A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    G = torch.randn(M, N, generator=g)
+    Ad, Bd, Gd = A.to(DEV), B.to(DEV), G.to(DEV)
+    flag = Fn.flag_bf16_exact(Ad)
+    assert int(flag[0].item()) == (1 if exact else 0)
+    C, _ = Fn.gemm_nt(Ad, Bd, a_exact_flag=flag)
+    ref = A.double() @ B.double().T
+    bound = (A.abs().double() @ B.abs().double().T) * 2e-6 + 1e-6
+    assert bool(((C.cpu().double() - ref).abs() <= bound).all())
+    dW = Fn.gemm_tn(Gd, Ad, b_exact_flag=flag)                      # (N,K) = G^T A
+    ref2 = G.double().T @ A.double()
+    bound2 = (G.abs().double().T @ A.abs().double()) * 2e-6 + 1e-6
+    assert bool(((dW.cpu().double() - ref2).abs() <= bound2).all())
+
+
 # ------------------------------------------------------------------------------------ cells
 def _cell_inputs(z, kind):
     p = {k: dev(z[k]).requires_grad_(True) for k in ("alpha", "beta", "a", "b", "V") if k in z}
