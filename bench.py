@@ -51,6 +51,24 @@ def algorithmic_work(name, B, T, H):
     return None
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950
+    FETCH_SIZE correction applied).  bench.py cannot run the profiler on itself; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    want = {"rec_cell_bwd": "rec_bwd_kernel", "rec_cell_fwd": "rec_fwd_kernel"}
+    for prefix, kname in want.items():
+        if kernel_label.startswith(prefix):
+            for k, v in table.items():
+                if k.startswith(kname):
+                    return v["hbm_bytes"]
+    return None
+
+
 def cpu_baseline(rank):
     """The oracle on the host cores, bounded sample of the same workload (same model, B=64 of 256)."""
     from oracle import snn_oracle as orc
@@ -179,7 +197,7 @@ def main():
             if bound == "mfma":
                 ach = amount / avg_s / 1e12
                 roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(dom),
                         "avg_ms": kern[dom]["avg_ms"]}
             else:
                 ach = amount / avg_s / 1e9

@@ -247,6 +247,60 @@ def test_recurrent_cell_bit_exact_with_dyadic_V(kind, spl, Bp, T, H):
     assert torch.equal(s.cpu(), ref), float((s.cpu() != ref).float().mean())
 
 
+@pytest.mark.parametrize("kind,B,T,H", [("adLIF", 5, 17, 64), ("LIF", 33, 9, 128), ("RadLIF", 5, 33, 64),
+                                        ("RLIF", 40, 21, 132), ("RadLIF", 48, 40, 1024)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_bidirectional_cell_addressing_bit_exact(kind, B, T, H, p_drop):
+    """dirs=2: virtual rows b' >= B read Wx time-flipped and write their spikes un-flipped into features
+    [H, 2H) (snns.py:252-254, 272-275), never materialising the flipped copy.  With dyadic V the spikes must
+    equal the oracle's explicit flip/cat/chunk/flip/cat bit for bit; with dropout every kept spike is
+    scaled and the kept pattern is a subset; the backward must match autograd through the oracle."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(B * 7 + H)
+    adaptive, recurrent = kind in ("adLIF", "RadLIF"), kind in ("RLIF", "RadLIF")
+    Wx = (torch.randn(B, T, H, generator=g) * 1.5 + 0.4).requires_grad_(True)
+    p = {"alpha": (torch.rand(H, generator=g) * 0.2 + 0.78).requires_grad_(True)}
+    if adaptive:
+        p.update(beta=(torch.rand(H, generator=g) * 0.05 + 0.95).requires_grad_(True),
+                 a=(torch.rand(H, generator=g) * 2.4 - 1.2).requires_grad_(True),
+                 b=(torch.rand(H, generator=g) * 2.4 - 0.2).requires_grad_(True))
+    if recurrent:
+        p["V"] = (torch.randint(-24, 25, (H, H), generator=g).float() / 64.0).requires_grad_(True)
+    u0 = torch.rand(2 * B, H, generator=g)
+    w0 = torch.rand(2 * B, H, generator=g) if adaptive else None
+    s0 = (torch.rand(2 * B, H, generator=g) < 0.3).float()
+    gs = torch.randn(B, T, 2 * H, generator=g)
+    # oracle: explicit glue around the cell
+    Wcat = torch.cat([Wx, Wx.flip(1)], dim=0)
+    s_cat = orc.spiking_cell(kind, Wcat, p, u0, w0, s0)
+    s_f, s_b = s_cat.chunk(2, dim=0)
+    ref = torch.cat([s_f, s_b.flip(1)], dim=2)
+    (ref * gs).sum().backward()
+    pd = {k: v.detach().to(DEV) for k, v in p.items()}
+    Wxd = Wx.detach().to(DEV)
+    seed = 1234567
+    s_out, count, saved = Fn.cell_forward(kind, Wxd, None, None, pd, u0.to(DEV), None if w0 is None else w0.to(DEV),
+                                          s0.to(DEV), B=B, dirs=2, theta=1.0, p_drop=p_drop, seed=seed)
+    Fn.check_status()
+    out = s_out.cpu()
+    if p_drop == 0.0:
+        assert torch.equal(out, ref.detach())
+        dWx, pg = Fn.cell_backward(kind, gs.to(DEV), None, pd, u0.to(DEV), None if w0 is None else w0.to(DEV),
+                                   s0.to(DEV), saved, B=B, dirs=2, T=T, H=H, theta=1.0, p_drop=0.0, seed=seed)
+        Fn.check_status()
+        dsum = (dWx[:B] + dWx[B:]).cpu().numpy()          # both directions share the projection rows
+        assert relmax(dsum, Wx.grad.numpy()) <= 2e-4
+        for k in p:
+            assert relmax(pg[k].cpu().numpy(), p[k].grad.numpy()) <= 2e-4, k
+    else:
+        keep = 1.0 / (1.0 - p_drop)
+        fired = ref.detach() > 0
+        assert bool(((out == 0) | ((out - keep).abs() < 1e-6)).all())
+        assert not bool((out > 0)[~fired].any())
+        assert abs(float((out > 0)[fired].float().mean()) - (1 - p_drop)) < 0.03
+    np.testing.assert_array_equal(count.cpu().numpy(), (out > 0).sum(dim=(0, 1)).numpy())
+
+
 @pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
 def test_recurrent_backward_vs_oracle_autograd(kind):
     """Backward on a trajectory the HIP forward and the oracle agree on exactly (dyadic V)."""
