@@ -100,7 +100,10 @@ __device__ __forceinline__ void stage_load(f32x4 (&r)[4], const float* __restric
 }
 
 // ---- registers -> LDS with conversion.  SPIKE: one plane of 0/1; else three planes hi/mid/lo.
-template <bool KM, bool SPIKE>
+// TRUNC: exact truncation split (x = t1 + t2 + t3; AND / SUB / v_perm, ~5 VALU per element) — used when the
+// other operand is an exact spike plane, where any exact split gives the same result; the dense 6-term
+// kernel keeps the round-to-nearest split, whose dropped cross terms are 8x smaller.
+template <bool KM, bool SPIKE, bool TRUNC = false>
 __device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short* __restrict__ S, int tid,
                                             int e_exact = 0) {
 #pragma unroll
@@ -119,6 +122,23 @@ __device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short*
                 w.y = (r[p].z != 0.f ? 0x3F80u : 0u) | (r[p].w != 0.f ? 0x3F800000u : 0u);
             }
             *reinterpret_cast<u32x2*>(S + off) = w;
+        } else if constexpr (TRUNC) {
+            u32x2 w1, w2, w3;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const unsigned x0 = __float_as_uint(r[p][2 * pr]), x1 = __float_as_uint(r[p][2 * pr + 1]);
+                const float r0 = r[p][2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+                const float r1 = r[p][2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                w1[pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                w2[pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                w3[pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            }
+            *reinterpret_cast<u32x2*>(S + off) = w1;
+            *reinterpret_cast<u32x2*>(S + PLANE + off) = w2;
+            *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = w3;
         } else {
             unsigned short h[4], m[4], l[4];
 #pragma unroll
@@ -143,14 +163,9 @@ __device__ __forceinline__ u32x4 frag_read(const unsigned short* __restrict__ S,
         const int col = idx_base + 16 * (g & 1) + 4 * p4;
         const int k0 = 16 * ks + 8 * (g >> 1);
         const unsigned short* a0 = S + (k0 + q) * KM_ROW + col;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * KM_ROW));
-        u32x4 o;
-        o.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-        o.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-        o.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-        o.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-        return o;
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0)));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * KM_ROW)));
+        return u32x4{lo.x, lo.y, hi.x, hi.y};  // already packed: element j in bits 16*(j&1) of dword j>>1
     }
 }
 
@@ -194,8 +209,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
     stage_load<B_KM>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
 
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        stage_store<A_KM, SPIKE_A>(ra, As, tid, g.e_exact);
-        stage_store<B_KM, SPIKE_B>(rb, Bs, tid, g.e_exact);
+        stage_store<A_KM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
+        stage_store<B_KM, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
         __syncthreads();
         if (k0 + BK < k_end) {
             stage_load<A_KM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
