@@ -228,19 +228,23 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             u64 gran[KGW];
             const u64 t_start = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
+                // all loads of the sweep are issued back to back (clamped index, no control flow between
+                // them) and only then compared: ONE round trip per sweep.  (A short-circuit `ok && tag==t`
+                // inside a per-k-group `if` made hipcc wait vmcnt(0) after every load: 8 serialized round
+                // trips, ~5.5k cycles per step — the largest single cost of the first versions.)
 #pragma unroll
                 for (int kk = 0; kk < KGW; ++kk) {
-                    const int kg = wave + 4 * kk;
-                    if (kg < a.n_ct) {
-                        gran[kk] = __hip_atomic_load(base + (size_t)kg * 32 + li, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && ((unsigned)(gran[kk] >> 32) == (unsigned)t);
-                    } else {
-                        gran[kk] = 0;
-                    }
+                    const int kgc = min(wave + 4 * kk, a.n_ct - 1);
+                    gran[kk] = __hip_atomic_load(base + (size_t)kgc * 32 + li, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (__all(ok)) break;
+                unsigned bad = 0;
+#pragma unroll
+                for (int kk = 0; kk < KGW; ++kk) {
+                    const unsigned m = (wave + 4 * kk < a.n_ct) ? 0xFFFFFFFFu : 0u;
+                    bad |= ((unsigned)(gran[kk] >> 32) ^ (unsigned)t) & m;
+                }
+                if (__all(bad == 0)) break;
                 if ((spins & 63u) == 63u &&
                     __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
                     raise_timeout(a.status, &abort_flag[t & 1]);
@@ -460,14 +464,18 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
             const u64 t_start = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
+                unsigned tg[KGW];
+#pragma unroll
+                for (int kk = 0; kk < KGW; ++kk)  // issue every tag load first, compare afterwards (see forward)
+                    tg[kk] = __hip_atomic_load(fl + min(wave + 4 * kk, a.n_ct - 1), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                unsigned bad = 0;
 #pragma unroll
                 for (int kk = 0; kk < KGW; ++kk) {
-                    const int kg = wave + 4 * kk;
-                    if (kg < a.n_ct)
-                        ok = ok && (__hip_atomic_load(fl + kg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want);
+                    const unsigned m = (wave + 4 * kk < a.n_ct) ? 0xFFFFFFFFu : 0u;
+                    bad |= (tg[kk] ^ want) & m;
                 }
-                if (__all(ok)) break;
+                if (__all(bad == 0)) break;
                 if ((spins & 63u) == 63u &&
                     __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
                     raise_timeout(a.status, &abort_flag[par]);
