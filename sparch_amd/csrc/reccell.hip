@@ -211,17 +211,31 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         return a.Wx + ((size_t)b * T + tt) * H + colc;
     };
     f32x4 x_next = ld4(wx_ptr(a.t_begin));
+    // Bulk HBM stores of a step are held back (12 VGPRs) and issued only after the NEXT step's poll loads:
+    // vmcnt retires in order and counts stores, so stores (and the Wx prefetch) issued ahead of the poll
+    // would put their HBM latency in front of the sweep.  Issued behind it they retire under the MFMA phase.
+    f32x4 pend_s = {0.f, 0.f, 0.f, 0.f}, pend_u = pend_s, pend_w = pend_s;
+    int pend_t = -1;
+    auto flush_pending = [&]() {
+        if (pend_t >= 0 && valid) {
+            const int ptt = d ? (T - 1 - pend_t) : pend_t;
+            st4(a.s_out + ((size_t)b * T + ptt) * HO + (size_t)d * H + colc, pend_s);
+            st4(a.u_save + ((size_t)bp * T + pend_t) * H + col, pend_u);
+            if (ADAPT) st4(a.w_save + ((size_t)bp * T + pend_t) * H + col, pend_w);
+        }
+        pend_t = -1;
+    };
     PROF_DECL
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         PROF_STAMP(-1);
         const f32x4 xv = x_next;
-        if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
 
         if (t == 0) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
+            if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
         } else {
             // ---- gather the 32 x H spike bits of step t-1 (tag == t) for this wave's k-groups
             const gu64* base = (const gu64*)a.chan + ((size_t)(t - 1) * a.n_rt_total + rt) * a.n_ct * 32;
@@ -253,6 +267,8 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_STAMP(0);  // poll wait
+            flush_pending();
+            if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
             // ---- s_{t-1} @ V on the bf16 MFMA: spikes expanded through the LDS table (lane
             //      (row li, k-half hh) takes byte 2*ks + hh of its row's 32-bit word)
             u32x4 af[KGW][2];
@@ -335,12 +351,12 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
                 so[e] = s[e] * k;
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
-            st4(a.s_out + o_out, so);
-            st4(a.u_save + ((size_t)bp * T + t) * H + col, uo);
-            if (ADAPT) st4(a.w_save + ((size_t)bp * T + t) * H + col, wo);
+            pend_s = so; pend_u = uo; pend_w = wo;
         }
-        PROF_STAMP(4);  // dropout + bulk stores issue
+        pend_t = t;
+        PROF_STAMP(4);  // dropout
     }
+    flush_pending();
     PROF_FLUSH(0)
 
     // ---- spike counts (post-dropout) -> one integer atomic per (direction, column) per workgroup
@@ -447,14 +463,16 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     };
     f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f};
     load_step(a.t_end - 1, g_nx, up_nx, wp_nx);
+    // (Unlike the forward, holding this kernel's fp32 stores / prefetch back until after the tag poll does
+    // not pay: measured 16.8k -> 18.2k cycles per step, the deferred traffic then competes with the tile loads.)
     PROF_DECL
 
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
         PROF_STAMP(-1);
         const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx;
-        if (t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
+        if (t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
 
         if (t + 1 < T) {
             // ---- wait for the dWx_{t+1} tiles of this wave's producers, then read them (sc1): all
