@@ -65,6 +65,17 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
 template <bool KM>
 __device__ __forceinline__ void stage_load(f32x4 (&r)[4], const float* __restrict__ P, int ld, int row0, int rows,
                                            int k0, int kend, int vec, int tid) {
+    // fast path (uniform): the whole 128 x 32 tile is in range and 16-byte loads are legal -> straight-line
+    // loads with no per-element exec-mask juggling
+    if (vec && row0 + 128 <= rows && k0 + BK <= kend) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + NT * p;
+            if constexpr (!KM) r[p] = *reinterpret_cast<const f32x4*>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
+            else               r[p] = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + (f >> 5)) * ld + row0 + ((f & 31) << 2));
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int f = tid + NT * p;
