@@ -130,9 +130,17 @@ def main():
     from sparch_amd import dp
     from sparch_amd import functional as Fn
 
-    rank, world, local = dp.init_from_env("nccl")
+    # RCCL ("nccl") is the real backend; SPARCH_DIST_BACKEND=gloo + SPARCH_SHARE_GPU=1 exist only to rehearse the
+    # multi-process code path on a one-GPU box (all ranks on cuda:0)
+    backend = os.environ.get("SPARCH_DIST_BACKEND", "nccl")
+    share = os.environ.get("SPARCH_SHARE_GPU", "0") == "1"
+    if share:
+        torch.cuda.set_device(0)
+    rank, world, local = dp.init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

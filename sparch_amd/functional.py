@@ -246,17 +246,20 @@ class _Norm:
         M, H = dy.shape
         dev = dy.device
         if mode == "batchnorm":
-            if not training:
-                raise NotImplementedError("sparch_amd: gradients through eval-mode BatchNorm are not supported")
-            mean, invstd = saved
+            mean, invstd = saved  # batch statistics (train) or running statistics (eval)
             dgamma = torch.empty(H, dtype=torch.float32, device=dev)
             dbeta = torch.empty(H, dtype=torch.float32, device=dev)
             nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_bn_bwd_reduce(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(dgamma),
                                            ptr(dbeta), ptr(ws), nbytes, _stream()), "sparch_bn_bwd_reduce")
+            if training:
+                cg, cb = dgamma, dbeta
+            else:  # fixed statistics: dx = dy * gamma * invstd, i.e. the batch-coupling terms vanish
+                cg = torch.zeros(H, dtype=torch.float32, device=dev)
+                cb = cg
             check(lib.sparch_bn_bwd_apply(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(weight),
-                                          ptr(dgamma), ptr(dbeta), ptr(dy), _stream()), "sparch_bn_bwd_apply")
+                                          ptr(cg), ptr(cb), ptr(dy), _stream()), "sparch_bn_bwd_apply")
             return dy, dgamma, dbeta
         if mode == "layernorm":
             mu, rstd = saved

@@ -493,6 +493,24 @@ def test_snn_train_step_vs_reference_golden(sp, name):
         assert np.abs(rates_e.cpu().numpy() - z["rates_eval"]).mean() <= 0.02
 
 
+def test_eval_mode_batchnorm_gradients_vs_oracle(sp):
+    """net.eval() with autograd on (fixed running statistics): gradients of a non-recurrent net must match
+    the oracle's autograd through F.batch_norm(training=False)."""
+    cfg, x, y, params, init, z = snn_case("snn_adLIF_bn")
+    net = _build(sp, cfg, params).eval()
+    torch.manual_seed(cfg["fwd_seed"])
+    out, rates = net(x.to(DEV))
+    loss = orc.train_step_loss(out, rates, y.to(DEV), use_regularizers=True)
+    loss.backward()
+    p = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in params.items()}
+    out_o, rates_o = orc.snn_forward(x, p, neuron_type=cfg["neuron_type"], num_layers=len(cfg["layer_sizes"]),
+                                     init_states=init, normalization="batchnorm", training=False)
+    orc.train_step_loss(out_o, rates_o, y, use_regularizers=True).backward()
+    assert np.abs(out.detach().cpu().numpy() - out_o.detach().numpy()).max() <= 2e-3 * cfg["T"]
+    for k, v in net.named_parameters():
+        assert relmax(v.grad.cpu().numpy(), p[k].grad.numpy()) <= 5e-2, k
+
+
 def test_cpu_tensors_raise_no_fallback(sp):
     net = sp.SNN((2, None, 16), [8, 8, 4], neuron_type="LIF")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
