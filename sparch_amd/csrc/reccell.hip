@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             u32x4 af[KGW][2];
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
-                const unsigned wbits = (unsigned)gran[kk];
+                // k-groups beyond H (padding of the register layout) contribute zero spikes; keeping the whole
+                // section free of branches lets the scheduler interleave LUT reads with the MFMA chain
+                const unsigned wbits = (wave + 4 * kk < a.n_ct) ? (unsigned)gran[kk] : 0u;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) af[kk][ks] = lut[(wbits >> (16 * ks + 8 * hh)) & 0xFFu];
             }
@@ -282,15 +284,11 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < KGW; ++kk) {
-                const int kg = wave + 4 * kk;
-                if (kg < a.n_ct) {
+            for (int kk = 0; kk < KGW; ++kk)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int p = 2; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
-                }
-            }
+                    for (int p = 2; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
             float* rd = red[t & 1][wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -526,8 +524,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
-                const int kg = wave + 4 * kk;
-                if (kg < a.n_ct) {
+                {   // branch-free on purpose (padding k-groups hold zeros): one basic block for the scheduler
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         // exact truncation split of the 8 fp32 values into three bf16 fragments
