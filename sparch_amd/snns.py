@@ -124,9 +124,11 @@ class _SpikingLayer(nn.Module):
     def _dropout_seed(self, device):
         """Counter-based seed for the in-kernel dropout mask: device generator seed (no sync)
         mixed with this layer's call count.  Masks differ from torch's by construction."""
-        self._calls += 1
+        # getattr defaults: modules un-pickled from a checkpoint written by the reference have neither field
+        self._calls = getattr(self, "_calls", 0) + 1
+        index = getattr(self, "_layer_index", 0)
         base = torch.cuda.initial_seed() if device.type == "cuda" else torch.initial_seed()
-        return (base * 0x9E3779B97F4A7C15 + (self._layer_index + 1) * 0x100000001B3 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        return (base * 0x9E3779B97F4A7C15 + (index + 1) * 0x100000001B3 + self._calls) & 0xFFFFFFFFFFFFFFFF
 
     def _cell_params(self):
         p = {"alpha": self.alpha}

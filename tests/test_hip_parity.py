@@ -511,6 +511,62 @@ def test_eval_mode_batchnorm_gradients_vs_oracle(sp):
         assert relmax(v.grad.cpu().numpy(), p[k].grad.numpy()) <= 5e-2, k
 
 
+def test_reference_written_checkpoint_runs_on_hip(sp):
+    """f-1: a checkpoint pickled by the reference loads through the shim and its eval forward on the HIP
+    path reproduces the reference's eval output (RadLIF: population statistics)."""
+    import os
+    from tests.golden_io import GOLDEN
+    net = torch.load(os.path.join(GOLDEN, "ref_checkpoint_RadLIF.pth"), weights_only=False).to(DEV)
+    z = load("ref_checkpoint_RadLIF_io")
+    x = torch.from_numpy(z["x"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        torch.manual_seed(2)
+        out, rates = net(x)
+    _Fn().check_status()
+    assert np.abs(rates.cpu().numpy() - z["rates_eval"]).mean() <= 0.02
+    assert np.abs(out.cpu().numpy() - z["out_eval"]).mean() <= 0.03 * 30 / 20 + 0.02
+    np.testing.assert_allclose(out.sum(1).cpu().numpy(), 30.0, rtol=1e-4)
+    net.train()                       # and it trains: dropout seed bookkeeping absent from the pickle
+    out, rates = net(x)
+    out.sum().backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def test_bidirectional_recurrent_multi_launch_full_width(sp):
+    """B' = 2*B = 512 virtual rows at H = 1024: 16 batch tiles, i.e. two persistent launches of 8 tiles x 32
+    workgroups per layer and direction-straddling state; invariants + determinism + linearity of the backward."""
+    Fn = _Fn()
+    torch.manual_seed(7)
+    B, T, C = 256, 40, 96
+    net = sp.SNN((B, None, C), [1024, 1024, 35], neuron_type="RadLIF", bidirectional=True).to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(B, T, C, generator=g) < 0.1).float().to(DEV)
+    y = torch.randint(0, 35, (B,), generator=g).to(DEV)
+
+    def step(scale):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        out, rates = net(x)
+        (torch.nn.functional.cross_entropy(out, y) * scale).backward()
+        Fn.check_status()
+        return out.detach(), rates.detach(), {k: v.grad.clone() for k, v in net.named_parameters()}
+
+    o1, r1, g1 = step(1.0)
+    assert r1.numel() == 2 * 2048 and float(r1.min()) >= 0 and float(r1.max()) <= 1 and float(r1.mean()) > 1e-3
+    np.testing.assert_allclose(o1.sum(1).cpu().numpy(), float(T), rtol=1e-4)
+    o2, r2, g2 = step(1.0)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    _, _, g3 = step(2.0)
+    assert all(torch.allclose(g3[k], 2.0 * g1[k], rtol=1e-5, atol=1e-9) for k in g1)
+    # flipping the input in time swaps the two directions' roles: rates of the two halves swap
+    torch.manual_seed(5)
+    lay = net.snn[0]
+    lay.eval()
+    with torch.no_grad():
+        torch.manual_seed(11); s_a, _ = lay.forward_with_rate(x)
+    assert s_a.shape == (B, T, 2048)
+
+
 def test_cpu_tensors_raise_no_fallback(sp):
     net = sp.SNN((2, None, 16), [8, 8, 4], neuron_type="LIF")
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -58,3 +58,18 @@ def test_spike_function_boxcar_semantics():
     assert s.tolist() == [0, 0, 0, 0, 1, 1, 1]            # strict > 0 (snns.py:29)
     s.sum().backward()
     assert x.grad.tolist() == [0, 0, 1, 1, 1, 1, 0]        # (-0.5, 0.5] (snns.py:34-35)
+
+
+def test_reference_written_checkpoint_loads_through_shim():
+    """Whole-module pickle written by the REAL reference (torch.save(self.net), exp.py:462; fixture made by
+    tools/gen_golden.py): un-pickles into this repo's classes via the `sparch.*` shim with identical weights.
+    weights_only=False is required for module pickles; the file is produced by our own generator script."""
+    import os
+    from tests.golden_io import GOLDEN, load
+    net = torch.load(os.path.join(GOLDEN, "ref_checkpoint_RadLIF.pth"), weights_only=False)
+    assert isinstance(net, sparch_amd.SNN) and isinstance(net.snn[0], sparch_amd.RadLIFLayer)
+    assert isinstance(net.snn[2], sparch_amd.ReadoutLayer) and net.is_snn and not net.training
+    z = load("ref_checkpoint_RadLIF_io")
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), z["param." + k]), k
+    assert net.snn[0].W.bias is not None and net.snn[0].dropout == 0.1

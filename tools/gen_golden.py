@@ -177,6 +177,27 @@ def gen_snn(name, neuron_type, layer_sizes, B, T, C, *, normalization="batchnorm
          **{"param." + k: v for k, v in params0.items()}, **states, **grads, **stats1)
 
 
+def gen_reference_checkpoint():
+    """A whole-module pickle exactly as the reference writes it (torch.save(self.net, ...), exp.py:462),
+    plus the eval-mode output it produces, to test that such checkpoints load through this repo's
+    `sparch.*` import shim and run on the HIP path."""
+    torch.manual_seed(99)
+    net = ref.SNN(input_shape=(4, None, 40), layer_sizes=[32, 32, 20], neuron_type="RadLIF", dropout=0.1,
+                  normalization="batchnorm", use_bias=True, bidirectional=False)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(4, 30, 40, generator=gen) < 0.2).float()
+    net.train()
+    torch.manual_seed(1)
+    net(x)  # one training forward so the BatchNorm running statistics are non-trivial
+    net.eval()
+    with torch.no_grad():
+        torch.manual_seed(2)
+        out, rates = net(x)
+    torch.save(net, os.path.join(OUT, "ref_checkpoint_RadLIF.pth"))
+    save("ref_checkpoint_RadLIF_io", x=npy(x).astype(np.uint8), out_eval=npy(out), rates_eval=npy(rates),
+         **{"param." + k: npy(v) for k, v in net.state_dict().items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -196,6 +217,7 @@ def main():
             normalization="layernorm", real_input=True)
     gen_snn("snn_LIF_noreadout", "LIF", [32, 24], 4, 20, 40,
             use_readout_layer=False, use_regularizers=False, p_in=0.2)
+    gen_reference_checkpoint()
 
 
 if __name__ == "__main__":
