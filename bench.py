@@ -33,12 +33,18 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured achievable)
 
-WORKLOAD = dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1)
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on (default)
+    "cfg3": dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
+    # BASELINE.json configs[1]: adLIF 3x512 on SHD shapes (HBM-bound fused cell kernels); informational
+    "cfg2": dict(neuron_type="adLIF", layer_sizes=[512, 512, 20], B=128, T=250, C=700, pdrop=0.1),
+}
+WORKLOAD = WORKLOADS["cfg3"]
 
 
 def algorithmic_work(name, B, T, H):
     """(bound, amount per launch, unit) for a timed call — SURVEY.md §8(d) figures, stated in DESIGN.md."""
-    m = re.match(r"gemm_(nt|nn|tn)\[(\d+)x(\d+)x(\d+)\]", name)
+    m = re.match(r"gemm_(?:spike_|auto_)?(nt|nn|tn)\[(\d+)x(\d+)x(\d+)\]", name)
     if m:
         M, N, K = int(m.group(2)), int(m.group(3)), int(m.group(4))
         return "mfma", 2.0 * M * N * K, "flop"
@@ -124,7 +130,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")
     args = ap.parse_args()
+    global WORKLOAD
+    WORKLOAD = WORKLOADS[args.workload]
 
     import sparch_amd
     from sparch_amd import dp
@@ -199,8 +208,9 @@ def main():
         kern = {k: {"launches": c, "avg_ms": t / c} for k, (c, t) in totals.items()}
         dom = max(totals.items(), key=lambda kv: kv[1][1])[0] if totals else None
         roof = None
-        if dom is not None:
-            bound, amount, _ = algorithmic_work(dom, B, T, H)
+        work = algorithmic_work(dom, B, T, H) if dom is not None else None
+        if work is not None:
+            bound, amount, _ = work
             avg_s = kern[dom]["avg_ms"] * 1e-3
             if bound == "mfma":
                 ach = amount / avg_s / 1e12
@@ -214,15 +224,17 @@ def main():
         print(f"[bench] gpu: {value:.0f} ts*samples/s, {ms:.2f} ms/step; dominant {dom}; "
               f"timing the CPU oracle sample next", file=sys.stderr, flush=True)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             cpu = cpu_baseline(rank)
         line = {
-            "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), RadLIF 3x1024 SSC shape",
+            "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " +
+                      ("RadLIF 3x1024 SSC shape" if args.workload == "cfg3" else "adLIF 3x512 SHD shape"),
             "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RadLIF [1024,1024,35] batchnorm pdrop=0.1, B=256/GPU T=250 C=700 "
-                                   "Bernoulli(0.05) spikes (BASELINE.json configs[2])",
+            "config": {"workload": f"{w['neuron_type']} {w['layer_sizes']} batchnorm pdrop={w['pdrop']}, B={B}/GPU "
+                                   f"T={T} C={C} Bernoulli(0.05) spikes (BASELINE.json "
+                                   f"configs[{2 if args.workload == 'cfg3' else 1}])",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["avg_ms"] * v["launches"] / args.steps, 4) for k, v in kern.items()},

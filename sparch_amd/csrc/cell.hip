@@ -19,7 +19,9 @@
 
 namespace {
 
-constexpr int U = 4;  // time steps of loads in flight per thread
+// time steps of loads in flight per thread: the small-problem (VEC = 1) variant runs at ~4 waves per CU and
+// needs a deep prefetch to cover HBM latency; the vector variant has 4x the bytes per load
+template <int VEC> struct Depth { static constexpr int U = VEC == 1 ? 16 : 8; };
 
 struct CellArgs {
     int B, dirs, T, H;
@@ -54,6 +56,7 @@ __device__ __forceinline__ void stv(float* p, const float (&d)[VEC]) {
 
 template <bool ADAPT, int VEC>
 __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
+    constexpr int U = Depth<VEC>::U;
     const int HQ = c.H / VEC;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Bp = c.B * c.dirs;
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
 
 template <bool ADAPT, int VEC>
 __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
+    constexpr int U = Depth<VEC>::U;
     const int HQ = c.H / VEC;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Bp = c.B * c.dirs;
