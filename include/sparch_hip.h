@@ -258,6 +258,17 @@ int sparch_fbank_frames(int n_samples);
 int sparch_fbank_fwd(int n_clips, int n_samples, int n_mels, const float* wave, float* out,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * f-3  SHD/SSC event lists -> dense binned spike counts (replaces SpikingDataset.__getitem__,
+ *      spiking_datasets.py:66-78: np.digitize into np.linspace(0, max_time, nb_steps) edges, then a
+ *      sparse->dense scatter in which duplicates add up).  Events of all samples are concatenated;
+ *      sample_offsets (n_samples+1, device int64) delimits them.  out (n_samples, nb_steps, nb_units) is
+ *      zeroed by the call.  Events the reference's sparse constructor would reject (t < 0, t >= max_time,
+ *      unit out of range) are skipped and counted in *n_dropped (device uint32).                    */
+int sparch_bin_events(long long n_events, const float* times, const int* units,
+                      const long long* sample_offsets, int n_samples, int nb_steps, int nb_units,
+                      double max_time, float* out, uint32_t* n_dropped, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

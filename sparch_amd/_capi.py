@@ -8,7 +8,7 @@ There is NO CPU fallback: if the library is missing or a call fails, we raise.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_uint64, c_void_p
 
 # PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be in the
 # process BEFORE libsparch_hip.so is dlopen'ed so that both bind ONE HIP runtime (one device
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "sparch_readout_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "sparch_fbank_frames": (c_int, [c_int]),
     "sparch_fbank_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
+    "sparch_bin_events": (c_int, [c_longlong, P, P, P, c_int, c_int, c_int, c_double, P, P, P]),
 }
 
 

@@ -570,3 +570,29 @@ def fbank(wave, num_mel_bins=40):
     check(lib.sparch_fbank_fwd(n_clips, n_samples, num_mel_bins, ptr(wave), ptr(out), _stream()),
           "sparch_fbank_fwd")
     return out
+
+
+def bin_events(times, units, nb_steps=100, nb_units=700, max_time=1.4, device="cuda"):
+    """Batch of event lists -> dense (B, nb_steps, nb_units) float32 spike counts on the device, as the
+    reference's SpikingDataset.__getitem__ builds them per sample on the CPU (spiking_datasets.py:66-78).
+    times / units: sequences (one entry per sample) of 1-D arrays or tensors.  Returns (x, n_dropped) where
+    n_dropped is a device int32 tensor counting events the reference would have rejected."""
+    import numpy as np
+
+    lens = [len(t) for t in times]
+    if len(lens) == 0 or len(units) != len(lens):
+        raise ValueError("bin_events: times and units must be non-empty sequences of equal length")
+    offs = torch.zeros(len(lens) + 1, dtype=torch.int64)
+    offs[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
+    n = int(offs[-1])
+    t_all = torch.from_numpy(np.concatenate([np.asarray(t, np.float32).ravel() for t in times]).astype(np.float32)) \
+        if n else torch.zeros(0, dtype=torch.float32)
+    u_all = torch.from_numpy(np.concatenate([np.asarray(u).ravel() for u in units]).astype(np.int32)) \
+        if n else torch.zeros(0, dtype=torch.int32)
+    dev = torch.device(device)
+    t_d, u_d, o_d = t_all.to(dev), u_all.to(dev), offs.to(dev)
+    out = torch.empty(len(lens), nb_steps, nb_units, dtype=torch.float32, device=dev)
+    dropped = torch.empty(4, dtype=torch.int32, device=dev)
+    check(lib.sparch_bin_events(n, ptr(t_d) if n else None, ptr(u_d) if n else None, ptr(o_d), len(lens), nb_steps,
+                                nb_units, float(max_time), ptr(out), ptr(dropped), _stream()), "sparch_bin_events")
+    return out, dropped[:1]
