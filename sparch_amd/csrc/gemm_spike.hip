@@ -187,7 +187,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // MODE 0: A is the spike operand; MODE 1: B is; MODE 2: both operands are dense fp32 and both are split
 // (six cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative).
 template <bool A_KM, bool B_KM, int MODE, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_spike_kernel(SArgs g) {
+__global__ __launch_bounds__(NT, 3) void gemm_spike_kernel(SArgs g) {
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
     constexpr int A_PLANES = SPIKE_A ? 1 : 3, B_PLANES = SPIKE_B ? 1 : 3;

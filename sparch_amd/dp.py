@@ -108,8 +108,10 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # SPARCH_DIST_BACKEND=gloo: rehearsal of the multi-process path without RCCL
+            backend = os.environ.get("SPARCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("SPARCH_SHARE_GPU", "0") == "1":
+            local = 0  # rehearsal on a one-GPU box: every rank on cuda:0
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

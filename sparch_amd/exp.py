@@ -88,6 +88,8 @@ class Experiment:
 
         if not torch.cuda.is_available():
             raise RuntimeError("sparch_amd: no HIP device visible; this build has no CPU training path")
+        if os.environ.get("SPARCH_SHARE_GPU", "0") == "1":
+            self.local_rank = 0
         self.device = torch.device("cuda", self.local_rank if self.world > 1 else 0)
         torch.cuda.set_device(self.device)
         logging.info(f"\nDevice is set to {self.device}\n")
