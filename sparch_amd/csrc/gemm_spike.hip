@@ -17,6 +17,8 @@
 //       -> MFMA fragment = one ds_read_b128 (conflict-free);
 //   KM operand (element (k,col) at p[k*ld+col]): LDS image [k][128 col] bf16, 320-byte rows
 //       -> MFMA fragment = two ds_read_b64_tr_b16 (hardware transpose read, conflict-free).
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -27,12 +29,43 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int BK = 32, NT = 256;
 constexpr int KC_ROW = 40;    // bf16 per LDS row of a KC image (32 + 8 pad = 80 B)
-constexpr int KM_ROW = 160;   // bf16 per LDS row of a KM image (128 + 32 pad = 320 B)
-constexpr int PLANE = (BM * KC_ROW > BK * KM_ROW) ? BM * KC_ROW : BK * KM_ROW;  // 5120 bf16 = 10 KiB
+// bf16 per LDS row of a KM image of a ROWS-wide operand tile: ROWS + 32 pad (128 -> 320 B, 256 -> 576 B;
+// both are 16 dwords mod the 64 banks, which is what makes the transposed reads conflict-free)
+template <int ROWS> constexpr int km_row() { return ROWS + 32; }
+template <bool KM, int ROWS> constexpr int plane_elems() { return KM ? BK * km_row<ROWS>() : ROWS * KC_ROW; }
 
 enum Epi { EPI_NONE = 0, EPI_BIAS = 1, EPI_STATS = 2 };
+
+// Diagnostic build only (-DSPARCH_REC_PROF): s_memtime stamps of the phases of one K-tile iteration
+#if defined(SPARCH_REC_PROF) && !defined(GA_NO_STAMPS)
+__device__ unsigned long long g_gemm_prof[8];
+#define GP_DECL                                                                                  \
+    unsigned long long gp_t = 0, gp_acc[5] = {0, 0, 0, 0, 0}, gp_c0, gp_r0;                      \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(gp_c0), "=s"(gp_r0)::"memory");
+#define GP_STAMP(i)                                                                              \
+    do {                                                                                         \
+        unsigned long long now_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((i) >= 0) gp_acc[(i) < 0 ? 0 : (i)] += now_ - gp_t;                                  \
+        gp_t = now_;                                                                             \
+    } while (0)
+#define GP_FLUSH()                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x == 7) {                                                   \
+        unsigned long long c1_, r1_;                                                             \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1_), "=s"(r1_)::"memory"); \
+        for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_gemm_prof[i_], gp_acc[i_]);                  \
+        atomicAdd(&g_gemm_prof[5], c1_ - gp_c0);                                                 \
+        atomicAdd(&g_gemm_prof[6], r1_ - gp_r0);                                                 \
+    }
+#else
+#define GP_DECL
+#define GP_STAMP(i)
+#define GP_FLUSH()
+#endif
 
 struct SArgs {
     const float* A; const float* B; float* C;
@@ -61,68 +94,75 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
     lo = bf16_bits(r2);
 }
 
-// ---- global -> registers (same thread/element map as gemm.hip)
-template <bool KM>
-__device__ __forceinline__ void stage_load(f32x4 (&r)[4], const float* __restrict__ P, int ld, int row0, int rows,
-                                           int k0, int kend, int vec, int tid) {
-    // fast path (uniform): the whole 128 x 32 tile is in range and 16-byte loads are legal -> straight-line
-    // loads with no per-element exec-mask juggling
-    if (vec && row0 + 128 <= rows && k0 + BK <= kend) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + NT * p;
-            if constexpr (!KM) r[p] = *reinterpret_cast<const f32x4*>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
-            else               r[p] = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + (f >> 5)) * ld + row0 + ((f & 31) << 2));
-        }
+// ---- global -> registers (same thread/element map as gemm.hip), one 16-byte piece `p` of the thread's
+// ROWS/32 pieces per call so that the K loop can spread the loads between its MFMA groups.
+// `fast` (uniform): the whole ROWS x 32 tile is in range and 16-byte loads are legal.
+template <bool KM, int ROWS>
+__device__ __forceinline__ bool tile_is_full(int row0, int rows, int k0, int kend, int vec) {
+    return vec && row0 + ROWS <= rows && k0 + BK <= kend;
+}
+template <bool KM, int ROWS>
+__device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const float* __restrict__ P, int ld,
+                                           int row0, int rows, int k0, int kend, int vec, int tid) {
+    constexpr int RQ = ROWS / 4;  // pieces per k row of a KM tile
+    const int f = tid + NT * p;
+    if (fast) {
+        if constexpr (!KM) out = *reinterpret_cast<const f32x4*>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
+        else               out = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + f / RQ) * ld + row0 + ((f % RQ) << 2));
         return;
     }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int f = tid + NT * p;
-        int row, k;
-        if constexpr (!KM) { row = row0 + (f >> 3); k = k0 + ((f & 7) << 2); }
-        else               { k = k0 + (f >> 5); row = row0 + ((f & 31) << 2); }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (!KM) {
-            if (row < rows) {
-                const float* q = P + (size_t)row * ld + k;
-                if (vec && k + 3 < kend) v = *reinterpret_cast<const f32x4*>(q);
-                else {
-                    if (k + 0 < kend) v.x = q[0];
-                    if (k + 1 < kend) v.y = q[1];
-                    if (k + 2 < kend) v.z = q[2];
-                    if (k + 3 < kend) v.w = q[3];
-                }
-            }
-        } else {
-            if (k < kend) {
-                const float* q = P + (size_t)k * ld + row;
-                if (vec && row + 3 < rows) v = *reinterpret_cast<const f32x4*>(q);
-                else {
-                    if (row + 0 < rows) v.x = q[0];
-                    if (row + 1 < rows) v.y = q[1];
-                    if (row + 2 < rows) v.z = q[2];
-                    if (row + 3 < rows) v.w = q[3];
-                }
+    int row, k;
+    if constexpr (!KM) { row = row0 + (f >> 3); k = k0 + ((f & 7) << 2); }
+    else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 2); }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!KM) {
+        if (row < rows) {
+            const float* q = P + (size_t)row * ld + k;
+            if (vec && k + 3 < kend) v = *reinterpret_cast<const f32x4*>(q);
+            else {
+                if (k + 0 < kend) v.x = q[0];
+                if (k + 1 < kend) v.y = q[1];
+                if (k + 2 < kend) v.z = q[2];
+                if (k + 3 < kend) v.w = q[3];
             }
         }
-        r[p] = v;
+    } else {
+        if (k < kend) {
+            const float* q = P + (size_t)k * ld + row;
+            if (vec && row + 3 < rows) v = *reinterpret_cast<const f32x4*>(q);
+            else {
+                if (row + 0 < rows) v.x = q[0];
+                if (row + 1 < rows) v.y = q[1];
+                if (row + 2 < rows) v.z = q[2];
+                if (row + 3 < rows) v.w = q[3];
+            }
+        }
     }
+    out = v;
+}
+template <bool KM, int ROWS>
+__device__ __forceinline__ void stage_load(f32x4 (&r)[ROWS / 32], const float* __restrict__ P, int ld, int row0,
+                                           int rows, int k0, int kend, int vec, int tid) {
+    const bool fast = tile_is_full<KM, ROWS>(row0, rows, k0, kend, vec);
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) load_piece<KM, ROWS>(r[p], p, fast, P, ld, row0, rows, k0, kend, vec, tid);
 }
 
 // ---- registers -> LDS with conversion.  SPIKE: one plane of 0/1; else three planes hi/mid/lo.
 // TRUNC: exact truncation split (x = t1 + t2 + t3; AND / SUB / v_perm, ~5 VALU per element) — used when the
 // other operand is an exact spike plane, where any exact split gives the same result; the dense 6-term
 // kernel keeps the round-to-nearest split, whose dropped cross terms are 8x smaller.
-template <bool KM, bool SPIKE, bool TRUNC = false>
-__device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short* __restrict__ S, int tid,
+template <bool KM, int ROWS, bool SPIKE, bool TRUNC = false>
+__device__ __forceinline__ void stage_store(const f32x4 (&r)[ROWS / 32], unsigned short* __restrict__ S, int tid,
                                             int e_exact = 0) {
+    constexpr int NP = ROWS / 32, RQ = ROWS / 4;
+    constexpr int PLANE = plane_elems<KM, ROWS>();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int f = tid + NT * p;
         int off;  // in bf16 elements, 8-byte aligned
         if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
-        else               off = (f >> 5) * KM_ROW + ((f & 31) << 2);
+        else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
         if constexpr (SPIKE) {
             u32x2 w;
             if (e_exact) {  // values are bf16-exact: their bf16 form is the upper half of the fp32 word
@@ -162,8 +202,12 @@ __device__ __forceinline__ void stage_store(const f32x4 (&r)[4], unsigned short*
 }
 
 // ---- MFMA fragment (8 bf16 of row/col `idx`, k = 16*ks + 8*h + j) from an LDS plane
-template <bool KM>
+template <bool KM, int ROWS>
 __device__ __forceinline__ u32x4 frag_read(const unsigned short* __restrict__ S, int idx_base, int lane, int ks) {
+    constexpr int KM_ROW = km_row<ROWS>();
+#if defined(SPARCH_REC_PROF) && defined(GA_NO_FRAG)  // ablation: no LDS fragment reads
+    return u32x4{(unsigned)lane, (unsigned)ks, (unsigned)idx_base, 0x3F803F80u};
+#endif
     if constexpr (!KM) {
         const int r = lane & 31, h = lane >> 5;
         return *reinterpret_cast<const u32x4*>(S + (idx_base + r) * KC_ROW + 16 * ks + 8 * h);
@@ -181,20 +225,45 @@ __device__ __forceinline__ u32x4 frag_read(const unsigned short* __restrict__ S,
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#if defined(SPARCH_REC_PROF) && defined(GA_NO_MFMA)  // ablation: keep the operands alive, drop the MFMA
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
+#if defined(SPARCH_REC_PROF) && defined(GA_FRAG_UNUSED)  // ablation: reads issued and waited for, MFMA on constants
+    asm volatile("" ::"v"(a), "v"(b));
+    const u32x4 k = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, k), c, 0, 0, 0);
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // MODE 0: A is the spike operand; MODE 1: B is; MODE 2: both operands are dense fp32 and both are split
 // (six cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative).
-template <bool A_KM, bool B_KM, int MODE, int EPI>
-__global__ __launch_bounds__(NT, 3) void gemm_spike_kernel(SArgs g) {
+//
+// Tile shape: 4 waves as 2 x 2, each wave owns WI x WJ MFMA tiles of 32 x 32, so the workgroup tile is
+// (64 WI) x (64 WJ).  Per 16-deep k step a wave reads pa*WI + pb*WJ fragments (1 KiB each) from LDS for
+// pa*pb-ish*WI*WJ MFMAs; at the old 2 x 2 shape that was 8 reads per 12 MFMAs = 85 B/clk/CU of LDS read
+// traffic at full MFMA rate against a 128 B/clk LDS — the measured limiter (ablation: dropping the
+// fragment reads took the TN kernel from 0.50 to 0.22 ms).  The spike-operand kernels therefore put 4 tiles
+// on the single-plane (spike) side and 2 on the three-plane side: 10 reads per 24 MFMAs.
+template <int MODE> struct Shape {
+    static constexpr int WI = MODE == 0 ? 4 : 2;
+    static constexpr int WJ = MODE == 1 ? 4 : 2;
+    static constexpr int BM = 64 * WI, BN = 64 * WJ;
+    static constexpr int OCC = (WI * WJ > 4) ? 2 : 3;  // workgroups per CU the register budget is set for
+};
+
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
+__global__ __launch_bounds__(NT, Shape<MODE>::OCC) void gemm_spike_kernel(SArgs g) {
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
+    constexpr int WI = Shape<MODE>::WI, WJ = Shape<MODE>::WJ, BM = Shape<MODE>::BM, BN = Shape<MODE>::BN;
     constexpr int A_PLANES = SPIKE_A ? 1 : 3, B_PLANES = SPIKE_B ? 1 : 3;
+    constexpr int PLANE_A = plane_elems<A_KM, BM>(), PLANE_B = plane_elems<B_KM, BN>();
     // one array (guide: keep all LDS in one object)
-    __shared__ __attribute__((aligned(16))) unsigned short lds[(A_PLANES + B_PLANES) * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short lds[A_PLANES * PLANE_A + B_PLANES * PLANE_B];
     unsigned short* As = lds;
-    unsigned short* Bs = lds + A_PLANES * PLANE;
+    unsigned short* Bs = lds + A_PLANES * PLANE_A;
 
     if (g.gate != nullptr && *g.gate != g.gate_want) return;  // uniform: every workgroup reads the same word
     const int tid = threadIdx.x;
@@ -202,98 +271,201 @@ __global__ __launch_bounds__(NT, 3) void gemm_spike_kernel(SArgs g) {
     const int li = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int k_begin = blockIdx.y * g.k_per_split;
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Renumber so
+    // that an XCD owns a CONTIGUOUS range of (split, tile_m, tile_n): tiles that share an operand panel
+    // then share one L2 instead of pulling the panel through all eight.
+    int lin = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lin = (lin & 7) * (gridDim.x >> 3) + (lin >> 3);
+    const int tiles_all = tiles_n * ((g.M + BM - 1) / BM);
+    const int split = lin / tiles_all, tile = lin - split * tiles_all;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    // FAST (host guarantees M >= BM, N >= BN, 16-byte loadable rows): an edge tile is SHIFTED back inside
+    // the matrix instead of being bounds-checked; it recomputes a few rows/columns of its neighbour and
+    // stores the same values again (same operands, same order: bit-identical), so the steady-state loop
+    // has no per-element predicates.
+    const int m0 = FAST ? min(tile_m * BM, g.M - BM) : tile_m * BM;
+    const int n0 = FAST ? min(tile_n * BN, g.N - BN) : tile_n * BN;
+    const int k_begin = split * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
 
-    f32x16 acc[2][2];
+    f32x16 acc[WI][WJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
-    stage_load<A_KM>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
-    stage_load<B_KM>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
+    constexpr int NPA = BM / 32, NPB = BN / 32;
+    f32x4 ra[NPA], rb[NPB];
+    int kn = 0;  // K offset of the tile the MFMA phase prefetches (FAST loop only)
 
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        stage_store<A_KM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
-        stage_store<B_KM, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
-        __syncthreads();
-        if (k0 + BK < k_end) {
-            stage_load<A_KM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
-            stage_load<B_KM>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
-        }
+    // The MFMA phase of one K tile.  The fragment reads run one group AHEAD of the MFMAs that use them
+    // (the first group's reads are issued right after the barrier) and, with LOADS, the 16-byte global
+    // loads of the next tile are spread over the groups: a wave's matrix pipe never waits on LDS latency
+    // and the vector-memory path is never handed 12 loads at once.  No branch inside: a branch is a
+    // basic-block boundary and the compiler's waitcnt insertion drains every outstanding load at one.
+    // (Ablation before this: fragment reads not overlapped with MFMA cost half the kernel time.)
+    auto mfma_phase = [&](auto loads_tag) __attribute__((always_inline)) {
+        constexpr bool LOADS = decltype(loads_tag)::value;
+        auto next_piece = [&](int q) __attribute__((always_inline)) {
+            if constexpr (LOADS) {
+                if (q < NPA) load_piece<A_KM, BM>(ra[q], q, true, g.A, g.lda, m0, g.M, kn, k_end, 1, tid);
+                else if (q < NPA + NPB) load_piece<B_KM, BN>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, kn, k_end, 1, tid);
+            }
+        };
+        if constexpr (MODE == 2) {
+            // both operands dense: a group = one 16-deep k step (6 terms x WI x WJ MFMAs), fragments double
+            // buffered across the two steps
+            u32x4 fa[2][WI][3], fb[2][WJ][3];
+            auto read_step = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if constexpr (MODE == 2) {
-                u32x4 fa[2][3], fb[2][3];
+                for (int i = 0; i < WI; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int p = 0; p < 3; ++p)
+                        fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fa[i][p] = frag_read<A_KM>(As + p * PLANE, wm * 64 + i * 32, lane, ks);
+                for (int j = 0; j < WJ; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int p = 0; p < 3; ++p)
+                        fb[ks][j][p] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
+            };
+            read_step(0);
+            constexpr int PPG = (NPA + NPB + 1) / 2;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fb[j][p] = frag_read<B_KM>(Bs + p * PLANE, wn * 64 + j * 32, lane, ks);
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int q = 0; q < PPG; ++q) next_piece(ks * PPG + q);
+                if (ks == 0) read_step(1);
+                __builtin_amdgcn_sched_barrier(0);
                 // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
                 constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
                 constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < WI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i][PA[c]], fb[j][PB[c]], acc[i][j]);
-            } else if constexpr (SPIKE_A) {
-                u32x4 fa[2], fb[2][3];
+                        for (int j = 0; j < WJ; ++j)
+                            acc[i][j] = mfma_bf16(fa[ks][i][PA[c]], fb[ks][j][PB[c]], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // one spike-side plane, three dense-side planes: a group = one plane of one k step
+            // (WI x WJ MFMAs); dense fragments double buffered by group, spike fragments re-read in place
+            // at the k-step boundary (the register budget for 2 workgroups per CU has no room for both)
+            constexpr int WS = SPIKE_A ? WI : WJ, WD = SPIKE_A ? WJ : WI;
+            u32x4 fs[WS], fd[2][WD];
+            auto read_spike = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = frag_read<A_KM>(As, wm * 64 + i * 32, lane, ks);
+                for (int i = 0; i < WS; ++i) {
+                    if constexpr (SPIKE_A) fs[i] = frag_read<A_KM, BM>(As, (wm * WI + i) * 32, lane, ks);
+                    else                   fs[i] = frag_read<B_KM, BN>(Bs, (wn * WJ + i) * 32, lane, ks);
+                }
+            };
+            auto read_dense = [&](int buf, int ks, int p) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < WD; ++j) {
+                    if constexpr (SPIKE_A) fd[buf][j] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
+                    else                   fd[buf][j] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + j) * 32, lane, ks);
+                }
+            };
+            read_spike(0);
+            read_dense(0, 0, 2);
+            constexpr int PPG = (NPA + NPB + 5) / 6;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fb[j][p] = frag_read<B_KM>(Bs + p * PLANE, wn * 64 + j * 32, lane, ks);
+            for (int gi = 0; gi < 6; ++gi) {
+                const int ks = gi / 3, p = 2 - gi % 3;  // smallest plane first
 #pragma unroll
-                for (int p = 2; p >= 0; --p)
+                for (int q = 0; q < PPG; ++q) next_piece(gi * PPG + q);
+                if (p > 0) read_dense((gi + 1) & 1, ks, p - 1);
+                else if (ks == 0) read_dense((gi + 1) & 1, 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j][p], acc[i][j]);
-            } else {
-                u32x4 fa[2][3], fb[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) fa[i][p] = frag_read<A_KM>(As + p * PLANE, wm * 64 + i * 32, lane, ks);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = frag_read<B_KM>(Bs, wn * 64 + j * 32, lane, ks);
-#pragma unroll
-                for (int p = 2; p >= 0; --p)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i][p], fb[j], acc[i][j]);
+                    for (int j = 0; j < WJ; ++j) {
+                        if constexpr (SPIKE_A) acc[i][j] = mfma_bf16(fs[i], fd[gi & 1][j], acc[i][j]);
+                        else                   acc[i][j] = mfma_bf16(fd[gi & 1][i], fs[j], acc[i][j]);
+                    }
+                if (p == 0 && ks == 0) read_spike(1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#if defined(SPARCH_REC_PROF) && defined(GA_NO_SPIKE_STAGE)  // ablation: spike operand costs nothing to stage
+        if constexpr (!SPIKE_A) stage_store<A_KM, BM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
+        if constexpr (!SPIKE_B) stage_store<B_KM, BN, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
+#elif !(defined(SPARCH_REC_PROF) && defined(GA_NO_STORE))
+        stage_store<A_KM, BM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
+        stage_store<B_KM, BN, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
+#endif
+    };
+
+    GP_DECL
+    if constexpr (FAST) {
+        // full tiles: [convert + LDS write] barrier [MFMA groups + next tile's loads] barrier
+        const int k_full = k_begin + (k_end - k_begin) / BK * BK;
+        if (k_begin < k_full) {
+            stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_begin, k_full, 1, tid);
+            stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_begin, k_full, 1, tid);
+        }
+        for (int k0 = k_begin; k0 < k_full; k0 += BK) {
+            GP_STAMP(-1);
+            store_tile();
+            GP_STAMP(0);  // wait for prefetched tile + convert + LDS write
+            __syncthreads();
+            GP_STAMP(1);  // barrier 1
+#if defined(SPARCH_REC_PROF) && defined(GA_NO_GLOAD)
+            kn = k_begin;
+#else
+            kn = (k0 + BK < k_full) ? k0 + BK : k0;  // after the last tile: fetch it again (in range, unused)
+#endif
+            mfma_phase(std::true_type{});
+            GP_STAMP(3);  // fragment reads + MFMA + next tile's loads
+            __syncthreads();
+            GP_STAMP(4);  // barrier 2
+        }
+        if (k_full < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
+            stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_full, k_end, 0, tid);
+            stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_full, k_end, 0, tid);
+            store_tile();
+            __syncthreads();
+            mfma_phase(std::false_type{});
+            __syncthreads();
+        }
+    } else {
+        // general shapes (small or unaligned operands): bounds-checked loads, issued before the MFMA phase
+        stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
+        stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            store_tile();
+            __syncthreads();
+            if (k0 + BK < k_end) {
+                stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
+                stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
+            }
+            mfma_phase(std::false_type{});
+            __syncthreads();
+        }
     }
+    GP_FLUSH()
 
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
-    float* Cz = g.C + (size_t)blockIdx.y * g.c_split_stride;
-    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    float* Cz = g.C + (size_t)split * g.c_split_stride;
+    float csum[WJ], csq[WJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + li;
+    for (int j = 0; j < WJ; ++j) {
+        csum[j] = 0.f; csq[j] = 0.f;
+        const int col = n0 + (wn * WJ + j) * 32 + li;
         float bj = 0.f;
         if constexpr (EPI & EPI_BIAS) bj = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + (wm * WI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[i][j][r] * g.scale;
                 if constexpr (EPI & EPI_BIAS) v = v + bj;
                 if (row < g.M && col < g.N) {
@@ -304,25 +476,40 @@ __global__ __launch_bounds__(NT, 3) void gemm_spike_kernel(SArgs g) {
         }
     }
     if constexpr (EPI & EPI_STATS) {
-        float* red = reinterpret_cast<float*>(lds);  // [2 (sum|sq)][2 (wm)][128] (2 KiB <= any LDS size here)
+        // column sum / sum of squares per 128-row block of C (the layout sparch_bn_finalize reads:
+        // [2 (sum|sq)][ceil(M/128)][N]).  A wave covers 32*WI rows: at WI = 4 that is one whole block,
+        // at WI = 2 the two wm halves of the workgroup add up to one.
+        float* red = reinterpret_cast<float*>(lds);  // [2 (sum|sq)][2 (wm)][BN] (<= 4 KiB)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WJ; ++j) {
             csum[j] += __shfl_xor(csum[j], 32);
             csq[j] += __shfl_xor(csq[j], 32);
         }
         if (h == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = wn * 64 + j * 32 + li;
-                red[(0 * 2 + wm) * 128 + c] = csum[j];
-                red[(1 * 2 + wm) * 128 + c] = csq[j];
+            for (int j = 0; j < WJ; ++j) {
+                const int c = (wn * WJ + j) * 32 + li;
+                red[(0 * 2 + wm) * BN + c] = csum[j];
+                red[(1 * 2 + wm) * BN + c] = csq[j];
             }
         }
         __syncthreads();
-        if (tid < 128 && n0 + tid < g.N && g.colstat != nullptr) {
-            const int tiles_m = (g.M + BM - 1) / BM;
-            g.colstat[(size_t)tile_m * g.N + n0 + tid] = red[0 * 128 + tid] + red[1 * 128 + tid];
-            g.colstat[(size_t)(tiles_m + tile_m) * g.N + n0 + tid] = red[2 * 128 + tid] + red[3 * 128 + tid];
+        if (tid < BN && n0 + tid < g.N && g.colstat != nullptr) {
+            const int blocks = (g.M + 127) / 128;
+            if constexpr (WI == 2) {
+                g.colstat[(size_t)tile_m * g.N + n0 + tid] = red[0 * BN + tid] + red[1 * BN + tid];
+                g.colstat[(size_t)(blocks + tile_m) * g.N + n0 + tid] = red[2 * BN + tid] + red[3 * BN + tid];
+            } else {
+                static_assert(WI == 2 || WI == 4, "colstat blocks are 128 rows");
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int blk = 2 * tile_m + w;
+                    if (blk < blocks) {
+                        g.colstat[(size_t)blk * g.N + n0 + tid] = red[(0 * 2 + w) * BN + tid];
+                        g.colstat[(size_t)(blocks + blk) * g.N + n0 + tid] = red[(1 * 2 + w) * BN + tid];
+                    }
+                }
+            }
         }
     }
 }
@@ -340,18 +527,40 @@ __global__ void splitk_reduce_kernel2(const float* __restrict__ ws, float* __res
     *c = accumulate ? (*c + s) : s;
 }
 
+// Split count of a TN product computed by the MODE kernel: one full round of co-resident workgroups (a
+// partial second round costs more than the shorter K range per workgroup gains).
+int target_wgs(int occ) {
+    static const int env = [] { const char* e = getenv("SPARCH_GEMM_TARGET_WGS"); return e ? atoi(e) : 0; }();
+    if (env > 0) return env;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    return occ * cus;
+}
+template <int MODE>
 int choose_splits(int M, int N, int K) {
-    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    const int tiles = cdiv(M, Shape<MODE>::BM) * cdiv(N, Shape<MODE>::BN);
     const int kt = cdiv(K, BK);
-    int s = 1;
-    while (tiles * s < 1024 && kt / (s * 2) >= 8) s *= 2;
-    return s;
+    int s = target_wgs(Shape<MODE>::OCC) / tiles;
+    if (s > kt / 8) s = kt / 8;
+    return s < 1 ? 1 : s;
 }
 
 template <bool A_KM, bool B_KM, int MODE, int EPI>
 int launch(SArgs& g, int splits, hipStream_t st) {
+    constexpr int BM = Shape<MODE>::BM, BN = Shape<MODE>::BN;
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-    hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI>), dim3(tiles, splits, 1), dim3(NT), 0, st, g);
+    // the shifted-edge-tile kernel needs whole tiles to exist, 16-byte rows, and (for the BatchNorm
+    // statistics, which are kept per 128-row block) no partial row tile
+    const bool fast = g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % 4 == 0) &&
+                      (!B_KM || g.N % 4 == 0) && (!(EPI & EPI_STATS) || g.M % BM == 0) &&
+                      g.k_per_split % BK == 0;
+    if (fast)
+        hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI, true>), dim3(tiles * splits, 1, 1), dim3(NT), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI, false>), dim3(tiles * splits, 1, 1), dim3(NT), 0, st, g);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
@@ -382,7 +591,7 @@ extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     if (spike_side != 0 && spike_side != 1) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int splits = choose_splits(M, N, K);
+    const int splits = spike_side == 0 ? choose_splits<0>(M, N, K) : choose_splits<1>(M, N, K);
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
     SArgs g{};
@@ -436,7 +645,7 @@ extern "C" int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, con
     SPARCH_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int splits = choose_splits(M, N, K);
+    const int splits = choose_splits<2>(M, N, K);
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
     SArgs g{};
@@ -512,7 +721,8 @@ extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda,
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N || !b_exact_flag)
         return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int splits = choose_splits(M, N, K);
+    // one split count for both gated kernels: only one of them runs, and the reduction needs one number
+    const int splits = choose_splits<1>(M, N, K);
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
     SArgs g{};
@@ -535,7 +745,18 @@ extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda,
     return SPARCH_OK;
 }
 
+#if defined(SPARCH_REC_PROF) && !defined(GA_NO_STAMPS)
+extern "C" int sparch_gemm_prof_read(unsigned long long* host_out, int reset) {
+    static unsigned long long zero[8];
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 extern "C" size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (size_t)choose_splits(M, N, K) * M * N * sizeof(float);
+    const int s0 = choose_splits<0>(M, N, K), s1 = choose_splits<1>(M, N, K), s2 = choose_splits<2>(M, N, K);
+    const int smax = s0 > s1 ? (s0 > s2 ? s0 : s2) : (s1 > s2 ? s1 : s2);
+    return (size_t)smax * M * N * sizeof(float);
 }

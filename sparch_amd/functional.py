@@ -180,9 +180,10 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b
     else:
         if spike_side is not None and spike_scale != 1.0:
             raise RuntimeError("internal: fp32 gemm_tn fallback expects unscaled operands")
-        nbytes = lib.sparch_gemm_tn_workspace_bytes(M, N, K)
+        split6 = DENSE_GEMM == "split6"
+        nbytes = (lib.sparch_gemm_spike_tn_workspace_bytes if split6 else lib.sparch_gemm_tn_workspace_bytes)(M, N, K)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
-        fn = lib.sparch_gemm6_tn if DENSE_GEMM == "split6" else lib.sparch_gemm_tn
+        fn = lib.sparch_gemm6_tn if split6 else lib.sparch_gemm_tn
         tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
         check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(zero_diag),
                  int(accumulate), ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
