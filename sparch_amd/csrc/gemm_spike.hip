@@ -29,7 +29,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int BK = 32, NT = 256;
+constexpr int BK = 32;
 constexpr int KC_ROW = 40;    // bf16 per LDS row of a KC image (32 + 8 pad = 80 B)
 // bf16 per LDS row of a KM image of a ROWS-wide operand tile: ROWS + 32 pad (128 -> 320 B, 256 -> 576 B;
 // both are 16 dwords mod the 64 banks, which is what makes the transposed reads conflict-free)
@@ -101,7 +101,7 @@ template <bool KM, int ROWS>
 __device__ __forceinline__ bool tile_is_full(int row0, int rows, int k0, int kend, int vec) {
     return vec && row0 + ROWS <= rows && k0 + BK <= kend;
 }
-template <bool KM, int ROWS>
+template <bool KM, int ROWS, int NT>
 __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const float* __restrict__ P, int ld,
                                            int row0, int rows, int k0, int kend, int vec, int tid) {
     constexpr int RQ = ROWS / 4;  // pieces per k row of a KM tile
@@ -140,67 +140,65 @@ __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const f
     }
     out = v;
 }
-template <bool KM, int ROWS>
-__device__ __forceinline__ void stage_load(f32x4 (&r)[ROWS / 32], const float* __restrict__ P, int ld, int row0,
+template <bool KM, int ROWS, int NT>
+__device__ __forceinline__ void stage_load(f32x4 (&r)[ROWS * 8 / NT], const float* __restrict__ P, int ld, int row0,
                                            int rows, int k0, int kend, int vec, int tid) {
     const bool fast = tile_is_full<KM, ROWS>(row0, rows, k0, kend, vec);
 #pragma unroll
-    for (int p = 0; p < ROWS / 32; ++p) load_piece<KM, ROWS>(r[p], p, fast, P, ld, row0, rows, k0, kend, vec, tid);
+    for (int p = 0; p < ROWS * 8 / NT; ++p)
+        load_piece<KM, ROWS, NT>(r[p], p, fast, P, ld, row0, rows, k0, kend, vec, tid);
 }
 
 // ---- registers -> LDS with conversion.  SPIKE: one plane of 0/1; else three planes hi/mid/lo.
 // TRUNC: exact truncation split (x = t1 + t2 + t3; AND / SUB / v_perm, ~5 VALU per element) — used when the
 // other operand is an exact spike plane, where any exact split gives the same result; the dense 6-term
 // kernel keeps the round-to-nearest split, whose dropped cross terms are 8x smaller.
-template <bool KM, int ROWS, bool SPIKE, bool TRUNC = false>
-__device__ __forceinline__ void stage_store(const f32x4 (&r)[ROWS / 32], unsigned short* __restrict__ S, int tid,
+template <bool KM, int ROWS, int NT, bool SPIKE, bool TRUNC = false>
+__device__ __forceinline__ void store_piece(const f32x4& r, int p, unsigned short* __restrict__ S, int tid,
                                             int e_exact = 0) {
-    constexpr int NP = ROWS / 32, RQ = ROWS / 4;
+    constexpr int RQ = ROWS / 4;
     constexpr int PLANE = plane_elems<KM, ROWS>();
+    const int f = tid + NT * p;
+    int off;  // in bf16 elements, 8-byte aligned
+    if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
+    else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
+    if constexpr (SPIKE) {
+        // e_exact (uniform): the values are bf16-exact and their bf16 form is the upper half of the fp32
+        // word; otherwise the plane holds (x != 0).  Both forms computed and selected by mask: a branch
+        // here would be a basic-block boundary between the MFMA groups of the pipelined loop.
+        const unsigned keep = e_exact ? 0xFFFFFFFFu : 0u;
+        u32x2 w;
+        w.x = (__builtin_amdgcn_perm(__float_as_uint(r.y), __float_as_uint(r.x), 0x07060302u) & keep) |
+              (((r.x != 0.f ? 0x3F80u : 0u) | (r.y != 0.f ? 0x3F800000u : 0u)) & ~keep);
+        w.y = (__builtin_amdgcn_perm(__float_as_uint(r.w), __float_as_uint(r.z), 0x07060302u) & keep) |
+              (((r.z != 0.f ? 0x3F80u : 0u) | (r.w != 0.f ? 0x3F800000u : 0u)) & ~keep);
+        *reinterpret_cast<u32x2*>(S + off) = w;
+    } else if constexpr (TRUNC) {
+        u32x2 w1, w2, w3;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int f = tid + NT * p;
-        int off;  // in bf16 elements, 8-byte aligned
-        if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
-        else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
-        if constexpr (SPIKE) {
-            u32x2 w;
-            if (e_exact) {  // values are bf16-exact: their bf16 form is the upper half of the fp32 word
-                w.x = __builtin_amdgcn_perm(__float_as_uint(r[p].y), __float_as_uint(r[p].x), 0x07060302u);
-                w.y = __builtin_amdgcn_perm(__float_as_uint(r[p].w), __float_as_uint(r[p].z), 0x07060302u);
-            } else {
-                w.x = (r[p].x != 0.f ? 0x3F80u : 0u) | (r[p].y != 0.f ? 0x3F800000u : 0u);
-                w.y = (r[p].z != 0.f ? 0x3F80u : 0u) | (r[p].w != 0.f ? 0x3F800000u : 0u);
-            }
-            *reinterpret_cast<u32x2*>(S + off) = w;
-        } else if constexpr (TRUNC) {
-            u32x2 w1, w2, w3;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const unsigned x0 = __float_as_uint(r[p][2 * pr]), x1 = __float_as_uint(r[p][2 * pr + 1]);
-                const float r0 = r[p][2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
-                const float r1 = r[p][2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
-                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
-                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
-                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
-                w1[pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-                w2[pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
-                w3[pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-            }
-            *reinterpret_cast<u32x2*>(S + off) = w1;
-            *reinterpret_cast<u32x2*>(S + PLANE + off) = w2;
-            *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = w3;
-        } else {
-            unsigned short h[4], m[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split3(r[p][e], h[e], m[e], l[e]);
-            *reinterpret_cast<u32x2*>(S + off) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-            *reinterpret_cast<u32x2*>(S + PLANE + off) = u32x2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
-            *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+        for (int pr = 0; pr < 2; ++pr) {
+            const unsigned x0 = __float_as_uint(r[2 * pr]), x1 = __float_as_uint(r[2 * pr + 1]);
+            const float r0 = r[2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+            const float r1 = r[2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+            const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+            const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+            const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+            w1[pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+            w2[pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+            w3[pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
         }
+        *reinterpret_cast<u32x2*>(S + off) = w1;
+        *reinterpret_cast<u32x2*>(S + PLANE + off) = w2;
+        *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = w3;
+    } else {
+        unsigned short h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(r[e], h[e], m[e], l[e]);
+        *reinterpret_cast<u32x2*>(S + off) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        *reinterpret_cast<u32x2*>(S + PLANE + off) = u32x2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+        *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
     }
 }
-
 // ---- MFMA fragment (8 bf16 of row/col `idx`, k = 16*ks + 8*h + j) from an LDS plane
 template <bool KM, int ROWS>
 __device__ __forceinline__ u32x4 frag_read(const unsigned short* __restrict__ S, int idx_base, int lane, int ks) {
@@ -246,30 +244,51 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // traffic at full MFMA rate against a 128 B/clk LDS — the measured limiter (ablation: dropping the
 // fragment reads took the TN kernel from 0.50 to 0.22 ms).  The spike-operand kernels therefore put 4 tiles
 // on the single-plane (spike) side and 2 on the three-plane side: 10 reads per 24 MFMAs.
-template <int MODE> struct Shape {
-    static constexpr int WI = MODE == 0 ? 4 : 2;
-    static constexpr int WJ = MODE == 1 ? 4 : 2;
-    static constexpr int BM = 64 * WI, BN = 64 * WJ;
-    static constexpr int OCC = (WI * WJ > 4) ? 2 : 3;  // workgroups per CU the register budget is set for
+template <int MODE, bool FAST> struct Shape {
+    // FAST: 8 waves (2 per SIMD, so that one wave's vector-memory issue stalls and barrier waits are
+    // covered by the other's MFMAs) in one workgroup per CU; general kernel: 4 waves, 2 workgroups per CU.
+    static constexpr int WM = FAST ? (MODE == 1 ? 4 : 2) : 2;   // waves along M
+    static constexpr int WN = FAST ? (MODE == 1 ? 2 : 4) : 2;   // waves along N
+    static constexpr int WI = FAST ? (MODE == 0 ? 4 : (MODE == 1 ? 1 : 2)) : 2;  // 32-row MFMA tiles per wave
+    static constexpr int WJ = FAST ? (MODE == 1 ? 4 : 1) : 2;
+    static constexpr int BM = 32 * WI * WM, BN = 32 * WJ * WN;
+    static constexpr int NT = 64 * WM * WN;
+    // workgroups per CU the register / LDS budget is set for
+    static constexpr int OCC = FAST ? 1 : (MODE == 2 ? 2 : 3);
 };
 
+extern __shared__ __attribute__((aligned(16))) unsigned short dyn_lds[];
+
+template <bool A_KM, bool B_KM, int MODE, bool FAST>
+constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of both operand tiles)
+    return (MODE == 0 ? 1 : 3) * plane_elems<A_KM, Shape<MODE, FAST>::BM>() +
+           (MODE == 1 ? 1 : 3) * plane_elems<B_KM, Shape<MODE, FAST>::BN>();
+}
+
+// FAST: one workgroup per CU (one wave per SIMD, up to 512 registers), TWO LDS stages, and the whole
+// pipeline of a K tile folded into its MFMA phase: while the 48 MFMAs of tile t run from stage t&1, the
+// same wave converts tile t+1 (already in registers) into the other stage and re-issues those registers'
+// loads for tile t+2 — VALU, LDS stores and global loads all go into the shadow of the MFMAs, and there
+// is one barrier per tile.  (With two workgroups per CU taking turns — convert phase, barrier, MFMA
+// phase, barrier — the matrix pipe was busy 47 % of the time: neither workgroup's latency chain was
+// short enough for two to cover each other.)
+// !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
-__global__ __launch_bounds__(NT, Shape<MODE>::OCC) void gemm_spike_kernel(SArgs g) {
+__global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
+    using S = Shape<MODE, FAST>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
-    constexpr int WI = Shape<MODE>::WI, WJ = Shape<MODE>::WJ, BM = Shape<MODE>::BM, BN = Shape<MODE>::BN;
+    constexpr int WI = S::WI, WJ = S::WJ, WN = S::WN, BM = S::BM, BN = S::BN, NT = S::NT;
     constexpr int A_PLANES = SPIKE_A ? 1 : 3, B_PLANES = SPIKE_B ? 1 : 3;
     constexpr int PLANE_A = plane_elems<A_KM, BM>(), PLANE_B = plane_elems<B_KM, BN>();
-    // one array (guide: keep all LDS in one object)
-    __shared__ __attribute__((aligned(16))) unsigned short lds[A_PLANES * PLANE_A + B_PLANES * PLANE_B];
-    unsigned short* As = lds;
-    unsigned short* Bs = lds + A_PLANES * PLANE_A;
+    constexpr int STAGE = stage_elems<A_KM, B_KM, MODE, FAST>();
+    unsigned short* const lds = dyn_lds;  // [FAST ? 2 : 1][A planes | B planes]
 
     if (g.gate != nullptr && *g.gate != g.gate_want) return;  // uniform: every workgroup reads the same word
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (g.N + BN - 1) / BN;
     // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Renumber so
     // that an XCD owns a CONTIGUOUS range of (split, tile_m, tile_n): tiles that share an operand panel
@@ -296,27 +315,32 @@ __global__ __launch_bounds__(NT, Shape<MODE>::OCC) void gemm_spike_kernel(SArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NPA = BM / 32, NPB = BN / 32;
+    constexpr int NPA = BM * 8 / NT, NPB = BN * 8 / NT;  // 16-byte pieces per thread and tile
     f32x4 ra[NPA], rb[NPB];
-    int kn = 0;  // K offset of the tile the MFMA phase prefetches (FAST loop only)
 
-    // The MFMA phase of one K tile.  The fragment reads run one group AHEAD of the MFMAs that use them
-    // (the first group's reads are issued right after the barrier) and, with LOADS, the 16-byte global
-    // loads of the next tile are spread over the groups: a wave's matrix pipe never waits on LDS latency
-    // and the vector-memory path is never handed 12 loads at once.  No branch inside: a branch is a
-    // basic-block boundary and the compiler's waitcnt insertion drains every outstanding load at one.
-    // (Ablation before this: fragment reads not overlapped with MFMA cost half the kernel time.)
-    auto mfma_phase = [&](auto loads_tag) __attribute__((always_inline)) {
-        constexpr bool LOADS = decltype(loads_tag)::value;
-        auto next_piece = [&](int q) __attribute__((always_inline)) {
-            if constexpr (LOADS) {
-                if (q < NPA) load_piece<A_KM, BM>(ra[q], q, true, g.A, g.lda, m0, g.M, kn, k_end, 1, tid);
-                else if (q < NPA + NPB) load_piece<B_KM, BN>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, kn, k_end, 1, tid);
-            }
-        };
+    // registers -> LDS stage at `st` (piece q of the NPA + NPB pieces a thread owns)
+    auto convert_piece = [&](int q, unsigned short* st) __attribute__((always_inline)) {
+        if (q < NPA) store_piece<A_KM, BM, NT, SPIKE_A, MODE != 2>(ra[q], q, st, tid, g.e_exact);
+        else if (q < NPA + NPB)
+            store_piece<B_KM, BN, NT, SPIKE_B, MODE != 2>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid, g.e_exact);
+    };
+    // global -> registers, full in-range tile at K offset k (FAST only)
+    auto fetch_piece = [&](int q, int k) __attribute__((always_inline)) {
+        if (q < NPA) load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
+        else if (q < NPA + NPB) load_piece<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
+    };
+
+    // The MFMA phase of one K tile held in the LDS stage `cur`.  Fragment reads run one group AHEAD of the
+    // MFMAs that use them.  `side(q)` is called once per piece q, spread evenly over the groups, in the
+    // same scheduling region as that group's MFMAs (FAST: convert piece q of the next tile and re-issue
+    // its load).  No branch inside: a branch is a basic-block boundary, and the compiler's waitcnt
+    // insertion drains every outstanding load at one.
+    auto mfma_phase = [&](const unsigned short* cur, auto side) __attribute__((always_inline)) {
+        const unsigned short* As = cur;
+        const unsigned short* Bs = cur + A_PLANES * PLANE_A;
         if constexpr (MODE == 2) {
-            // both operands dense: a group = one 16-deep k step (6 terms x WI x WJ MFMAs), fragments double
-            // buffered across the two steps
+            // both operands dense: six cross terms per 16-deep k step; all fragments of a step are read at
+            // once and double buffered across the two steps; a group = one term (WI x WJ MFMAs)
             u32x4 fa[2][WI][3], fb[2][WJ][3];
             auto read_step = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -331,36 +355,38 @@ __global__ __launch_bounds__(NT, Shape<MODE>::OCC) void gemm_spike_kernel(SArgs 
                         fb[ks][j][p] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
             };
             read_step(0);
-            constexpr int PPG = (NPA + NPB + 1) / 2;
+            constexpr int PPG = (NPA + NPB + 11) / 12;
+            // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+            constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int q = 0; q < PPG; ++q) next_piece(ks * PPG + q);
-                if (ks == 0) read_step(1);
-                __builtin_amdgcn_sched_barrier(0);
-                // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
-                constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
-                constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+                for (int c = 0; c < 6; ++c) {
+                    if (ks == 0 && c == 0) read_step(1);
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
+                    for (int q = 0; q < PPG; ++q) side((ks * 6 + c) * PPG + q);
 #pragma unroll
                     for (int i = 0; i < WI; ++i)
 #pragma unroll
                         for (int j = 0; j < WJ; ++j)
                             acc[i][j] = mfma_bf16(fa[ks][i][PA[c]], fb[ks][j][PB[c]], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
             // one spike-side plane, three dense-side planes: a group = one plane of one k step
-            // (WI x WJ MFMAs); dense fragments double buffered by group, spike fragments re-read in place
-            // at the k-step boundary (the register budget for 2 workgroups per CU has no room for both)
+            // (WI x WJ MFMAs); dense fragments double buffered by group, spike fragments by k step
+            // (the general kernel's 2-workgroup register budget has no room for the second spike buffer:
+            // there the spike fragments are re-read in place at the k-step boundary)
             constexpr int WS = SPIKE_A ? WI : WJ, WD = SPIKE_A ? WJ : WI;
-            u32x4 fs[WS], fd[2][WD];
+            constexpr int SB = FAST ? 2 : 1;
+            u32x4 fs[SB][WS], fd[2][WD];
             auto read_spike = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < WS; ++i) {
-                    if constexpr (SPIKE_A) fs[i] = frag_read<A_KM, BM>(As, (wm * WI + i) * 32, lane, ks);
-                    else                   fs[i] = frag_read<B_KM, BN>(Bs, (wn * WJ + i) * 32, lane, ks);
+                    if constexpr (SPIKE_A) fs[ks % SB][i] = frag_read<A_KM, BM>(As, (wm * WI + i) * 32, lane, ks);
+                    else                   fs[ks % SB][i] = frag_read<B_KM, BN>(Bs, (wn * WJ + i) * 32, lane, ks);
                 }
             };
             auto read_dense = [&](int buf, int ks, int p) __attribute__((always_inline)) {
@@ -376,77 +402,78 @@ __global__ __launch_bounds__(NT, Shape<MODE>::OCC) void gemm_spike_kernel(SArgs 
 #pragma unroll
             for (int gi = 0; gi < 6; ++gi) {
                 const int ks = gi / 3, p = 2 - gi % 3;  // smallest plane first
-#pragma unroll
-                for (int q = 0; q < PPG; ++q) next_piece(gi * PPG + q);
                 if (p > 0) read_dense((gi + 1) & 1, ks, p - 1);
-                else if (ks == 0) read_dense((gi + 1) & 1, 1, 2);
-                __builtin_amdgcn_sched_barrier(0);
+                else if (ks == 0) { if constexpr (SB == 2) read_spike(1); read_dense((gi + 1) & 1, 1, 2); }
+#pragma unroll
+                for (int q = 0; q < PPG; ++q) side(gi * PPG + q);
 #pragma unroll
                 for (int i = 0; i < WI; ++i)
 #pragma unroll
                     for (int j = 0; j < WJ; ++j) {
-                        if constexpr (SPIKE_A) acc[i][j] = mfma_bf16(fs[i], fd[gi & 1][j], acc[i][j]);
-                        else                   acc[i][j] = mfma_bf16(fd[gi & 1][i], fs[j], acc[i][j]);
+                        if constexpr (SPIKE_A) acc[i][j] = mfma_bf16(fs[ks % SB][i], fd[gi & 1][j], acc[i][j]);
+                        else                   acc[i][j] = mfma_bf16(fd[gi & 1][i], fs[ks % SB][j], acc[i][j]);
                     }
-                if (p == 0 && ks == 0) read_spike(1);
+                if constexpr (SB == 1) { if (p == 0 && ks == 0) read_spike(1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    auto store_tile = [&]() __attribute__((always_inline)) {
-#if defined(SPARCH_REC_PROF) && defined(GA_NO_SPIKE_STAGE)  // ablation: spike operand costs nothing to stage
-        if constexpr (!SPIKE_A) stage_store<A_KM, BM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
-        if constexpr (!SPIKE_B) stage_store<B_KM, BN, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
-#elif !(defined(SPARCH_REC_PROF) && defined(GA_NO_STORE))
-        stage_store<A_KM, BM, SPIKE_A, MODE != 2>(ra, As, tid, g.e_exact);
-        stage_store<B_KM, BN, SPIKE_B, MODE != 2>(rb, Bs, tid, g.e_exact);
-#endif
-    };
+    auto no_side = [](int) __attribute__((always_inline)) {};
 
     GP_DECL
     if constexpr (FAST) {
-        // full tiles: [convert + LDS write] barrier [MFMA groups + next tile's loads] barrier
-        const int k_full = k_begin + (k_end - k_begin) / BK * BK;
-        if (k_begin < k_full) {
-            stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_begin, k_full, 1, tid);
-            stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_begin, k_full, 1, tid);
-        }
-        for (int k0 = k_begin; k0 < k_full; k0 += BK) {
-            GP_STAMP(-1);
-            store_tile();
-            GP_STAMP(0);  // wait for prefetched tile + convert + LDS write
+        const int nt = (k_end - k_begin) / BK;  // full tiles
+        if (nt > 0) {
+            // prologue: tile 0 -> stage 0, tile 1 -> registers
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) fetch_piece(q, k_begin);
+            const int k1 = nt > 1 ? k_begin + BK : k_begin;
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) { convert_piece(q, lds); fetch_piece(q, k1); }
             __syncthreads();
-            GP_STAMP(1);  // barrier 1
-#if defined(SPARCH_REC_PROF) && defined(GA_NO_GLOAD)
-            kn = k_begin;
-#else
-            kn = (k0 + BK < k_full) ? k0 + BK : k0;  // after the last tile: fetch it again (in range, unused)
+            for (int t = 0; t + 1 < nt; ++t) {
+                GP_STAMP(-1);
+                const unsigned short* cur = lds + (t & 1) * STAGE;
+                unsigned short* nxt = lds + ((t + 1) & 1) * STAGE;
+                // tile t+2 (after the last one: fetch the last tile again — in range, never used)
+                const int k2 = k_begin + min(t + 2, nt - 1) * BK;
+                mfma_phase(cur, [&](int q) __attribute__((always_inline)) {
+#if !(defined(SPARCH_REC_PROF) && defined(GA_NO_STORE))
+                    convert_piece(q, nxt);
 #endif
-            mfma_phase(std::true_type{});
-            GP_STAMP(3);  // fragment reads + MFMA + next tile's loads
+#if !(defined(SPARCH_REC_PROF) && defined(GA_NO_GLOAD))
+                    fetch_piece(q, k2);
+#endif
+                });
+                GP_STAMP(3);  // MFMA phase with the next tile's conversion and the loads after it
+                __syncthreads();
+                GP_STAMP(4);  // barrier
+            }
+            mfma_phase(lds + ((nt - 1) & 1) * STAGE, no_side);
             __syncthreads();
-            GP_STAMP(4);  // barrier 2
         }
-        if (k_full < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
-            stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_full, k_end, 0, tid);
-            stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_full, k_end, 0, tid);
-            store_tile();
+        const int k_tail = k_begin + nt * BK;
+        if (k_tail < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
+            stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
+            stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
             __syncthreads();
-            mfma_phase(std::false_type{});
+            mfma_phase(lds, no_side);
             __syncthreads();
         }
     } else {
-        // general shapes (small or unaligned operands): bounds-checked loads, issued before the MFMA phase
-        stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
-        stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
+        stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
+        stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-            store_tile();
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
             __syncthreads();
             if (k0 + BK < k_end) {
-                stage_load<A_KM, BM>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
-                stage_load<B_KM, BN>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
+                stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
+                stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
             }
-            mfma_phase(std::false_type{});
+            mfma_phase(lds, no_side);
             __syncthreads();
         }
     }
@@ -541,28 +568,40 @@ int target_wgs(int occ) {
 }
 template <int MODE>
 int choose_splits(int M, int N, int K) {
-    const int tiles = cdiv(M, Shape<MODE>::BM) * cdiv(N, Shape<MODE>::BN);
+    const int tiles = cdiv(M, Shape<MODE, true>::BM) * cdiv(N, Shape<MODE, true>::BN);
     const int kt = cdiv(K, BK);
-    int s = target_wgs(Shape<MODE>::OCC) / tiles;
+    int s = target_wgs(1) / tiles;  // the pipelined kernel runs one workgroup per CU
     if (s > kt / 8) s = kt / 8;
     return s < 1 ? 1 : s;
 }
 
 template <bool A_KM, bool B_KM, int MODE, int EPI>
-int launch(SArgs& g, int splits, hipStream_t st) {
-    constexpr int BM = Shape<MODE>::BM, BN = Shape<MODE>::BN;
-    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+bool fast_ok(const SArgs& g) {
+    constexpr int BM = Shape<MODE, true>::BM, BN = Shape<MODE, true>::BN;
     // the shifted-edge-tile kernel needs whole tiles to exist, 16-byte rows, and (for the BatchNorm
     // statistics, which are kept per 128-row block) no partial row tile
-    const bool fast = g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % 4 == 0) &&
-                      (!B_KM || g.N % 4 == 0) && (!(EPI & EPI_STATS) || g.M % BM == 0) &&
-                      g.k_per_split % BK == 0;
-    if (fast)
-        hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI, true>), dim3(tiles * splits, 1, 1), dim3(NT), 0, st, g);
-    else
-        hipLaunchKernelGGL((gemm_spike_kernel<A_KM, B_KM, MODE, EPI, false>), dim3(tiles * splits, 1, 1), dim3(NT), 0, st, g);
+    return g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % 4 == 0) && (!B_KM || g.N % 4 == 0) &&
+           (!(EPI & EPI_STATS) || g.M % BM == 0) && g.k_per_split % BK == 0 &&
+           g.k_per_split >= 8 * BK;  // a short K range never fills the pipeline: general kernel, 2 workgroups per CU
+}
+
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
+int launch_variant(SArgs& g, int splits, hipStream_t st) {
+    const int wgs = cdiv(g.M, Shape<MODE, FAST>::BM) * cdiv(g.N, Shape<MODE, FAST>::BN) * splits;
+    constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
+    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
+    hipLaunchKernelGGL(kernel, dim3(wgs, 1, 1), dim3(Shape<MODE, FAST>::NT), lds_bytes, st, g);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
+}
+
+template <bool A_KM, bool B_KM, int MODE, int EPI>
+int launch(SArgs& g, int splits, hipStream_t st) {
+    if (fast_ok<A_KM, B_KM, MODE, EPI>(g)) return launch_variant<A_KM, B_KM, MODE, EPI, true>(g, splits, st);
+    return launch_variant<A_KM, B_KM, MODE, EPI, false>(g, splits, st);
 }
 
 }  // namespace
