@@ -57,6 +57,20 @@ constexpr int CT = 32;       // columns per workgroup (= one k-group of its cons
 constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
 constexpr int RING = 4;      // depth of the backward hand-off ring (2 suffices, see header)
 constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
+// Scope of the hand-off accesses.  Experiment hooks (diagnostic builds only); the shipped values are
+// agent scope / sc1, the only combination that is correct for any placement of the workgroups.
+#ifndef REC_LD_SCOPE
+#define REC_LD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#ifndef REC_ST_SCOPE
+#define REC_ST_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#ifndef REC_LD_AUX
+#define REC_LD_AUX 16 /* sc1 */
+#endif
+#ifndef REC_ST_AUX
+#define REC_ST_AUX 16 /* sc1 */
+#endif
 constexpr u64 TIMEOUT_TICKS = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
 struct RecArgs {
@@ -249,8 +263,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < KGW; ++kk) {
                     const int kgc = min(wave + 4 * kk, a.n_ct - 1);
-                    gran[kk] = __hip_atomic_load(base + (size_t)kgc * 32 + li, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    gran[kk] = __hip_atomic_load(base + (size_t)kgc * 32 + li, __ATOMIC_RELAXED, REC_LD_SCOPE);
                 }
                 unsigned bad = 0;
 #pragma unroll
@@ -335,8 +348,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         word |= __shfl_xor(word, 4);
         if (cq == 0 && t + 1 < T) {
             gu64* slot = (gu64*)a.chan + (((size_t)t * a.n_rt_total + rt) * a.n_ct + ct) * 32 + r;
-            __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
         PROF_STAMP(3);  // pointwise + publish
         if (valid) {
@@ -374,12 +386,20 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
 }
 
 // ------------------------------------------------------------------------------ backward
-template <bool ADAPT, int KGW>
-__global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][4][RT * RED_LD];
+// NW waves per workgroup, each contracting over its own k-groups (kg = wave + NW*kk) into a partial
+// 32 x 32 tile that is summed through LDS.  NW = 8 (two waves per SIMD) whenever there are enough k-groups:
+// per step a SIMD has 112 MFMAs, ~770 VALU instructions of splitting and 32 tile loads to issue, and with
+// a single wave those queue behind each other (and behind the first load's latency); two waves fill each
+// other's stalls.  The pointwise reverse step and the stores stay on the first 256 threads.
+template <bool ADAPT, int KGW, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
-    __shared__ __attribute__((aligned(16))) u32x4 vlo[4][KGW][2][64];
+    __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
+    // per-thread neuron constants (alpha, beta, a, b, rate gradient of the thread's 4 columns): kept in LDS
+    // and re-read each step — the 8-wave kernel's 256-register budget has no room to hold them
+    __shared__ __attribute__((aligned(16))) f32x4 pconst[5][256];
     __shared__ int abort_flag[2];
 
     const int tid = threadIdx.x;
@@ -390,16 +410,17 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     const int ct = (int)(blockIdx.x / a.n_rt_launch);
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
 
-    const int r = tid >> 3, cq = tid & 7;
+    const bool pw = tid < 256;  // threads that own a (row, 4 columns) piece of the tile's pointwise state
+    const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
-    const bool valid = bp < a.Bp && col < H;
+    const bool valid = pw && bp < a.Bp && col < H;
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
     u32x4 vb[KGW][2][2];
 #pragma unroll
     for (int kk = 0; kk < KGW; ++kk) {
-        const int kg = wave + 4 * kk;
+        const int kg = wave + NW * kk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const u32x4* src = a.vpack + ((((size_t)ct * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
@@ -409,16 +430,21 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         }
     }
 
-    float al[4], oma[4], be[4], pa[4], pb[4], gr[4];
     float du_n[4], dw_n[4], u_t[4], acc_al[4], acc_be[4], acc_a[4], acc_b[4];
+    if (pw) {
+        f32x4 c_al, c_be, c_a, c_b, c_gr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c_al[e] = clampf(a.alpha[colc + e], SP_ALPHA_LO, SP_ALPHA_HI);
+            c_be[e] = ADAPT ? clampf(a.beta[colc + e], SP_BETA_LO, SP_BETA_HI) : 0.f;
+            c_a[e] = ADAPT ? clampf(a.a[colc + e], SP_A_LO, SP_A_HI) : 0.f;
+            c_b[e] = ADAPT ? clampf(a.b[colc + e], SP_B_LO, SP_B_HI) : 0.f;
+            c_gr[e] = a.g_rate ? a.g_rate[(size_t)d * H + colc + e] * a.g_rate_scale : 0.0f;
+        }
+        pconst[0][tid] = c_al; pconst[1][tid] = c_be; pconst[2][tid] = c_a; pconst[3][tid] = c_b; pconst[4][tid] = c_gr;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        al[e] = clampf(a.alpha[colc + e], SP_ALPHA_LO, SP_ALPHA_HI);
-        oma[e] = 1.0f - al[e];
-        be[e] = ADAPT ? clampf(a.beta[colc + e], SP_BETA_LO, SP_BETA_HI) : 0.f;
-        pa[e] = ADAPT ? clampf(a.a[colc + e], SP_A_LO, SP_A_HI) : 0.f;
-        pb[e] = ADAPT ? clampf(a.b[colc + e], SP_B_LO, SP_B_HI) : 0.f;
-        gr[e] = a.g_rate ? a.g_rate[(size_t)d * H + colc + e] * a.g_rate_scale : 0.0f;
         du_n[e] = dw_n[e] = 0.f;
         acc_al[e] = acc_be[e] = acc_a[e] = acc_b[e] = 0.f;
     }
@@ -460,7 +486,9 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         }
     };
     f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f};
-    load_step(a.t_end - 1, g_nx, up_nx, wp_nx);
+    f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    g_nx = up_nx = zero4;
+    if (pw) load_step(a.t_end - 1, g_nx, up_nx, wp_nx);
     // (Unlike the forward, holding this kernel's fp32 stores / prefetch back until after the tag poll does
     // not pay: measured 16.8k -> 18.2k cycles per step, the deferred traffic then competes with the tile loads.)
     PROF_DECL
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx;
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
-        if (t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
+        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
 
         if (t + 1 < T) {
             // ---- wait for the dWx_{t+1} tiles of this wave's producers, then read them (sc1): all
@@ -478,27 +506,26 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             const unsigned slot = (unsigned)((t + 1) % RING);
             const unsigned want = (unsigned)(T - (t + 1));
             const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
-            const u64 t_start = __builtin_amdgcn_s_memrealtime();
-            for (unsigned spins = 0;; ++spins) {
-                unsigned tg[KGW];
-#pragma unroll
-                for (int kk = 0; kk < KGW; ++kk)  // issue every tag load first, compare afterwards (see forward)
-                    tg[kk] = __hip_atomic_load(fl + min(wave + 4 * kk, a.n_ct - 1), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                unsigned bad = 0;
-#pragma unroll
-                for (int kk = 0; kk < KGW; ++kk) {
-                    const unsigned m = (wave + 4 * kk < a.n_ct) ? 0xFFFFFFFFu : 0u;
-                    bad |= (tg[kk] ^ want) & m;
+            // ONE wave polls, one 128-byte load per sweep (lane i reads the tag of producer column tile i);
+            // the others wait at the barrier.  (Every wave polling its own producers' tags put 8 x 4
+            // agent-scope loads per workgroup per sweep on the one memory channel that holds a row tile's
+            // tag line, and the producers' tag stores queued behind them.)
+            if (wave == 0) {
+                const u64 t_start = __builtin_amdgcn_s_memrealtime();
+                const unsigned m = (lane < a.n_ct) ? 0xFFFFFFFFu : 0u;
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned tg = __hip_atomic_load(fl + min(lane, a.n_ct - 1), __ATOMIC_RELAXED, REC_LD_SCOPE);
+                    if (__all(((tg ^ want) & m) == 0)) break;
+                    if ((spins & 63u) == 63u &&
+                        __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                        raise_timeout(a.status, &abort_flag[par]);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (__all(bad == 0)) break;
-                if ((spins & 63u) == 63u &&
-                    __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                    raise_timeout(a.status, &abort_flag[par]);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
             }
+            __syncthreads();
+            if (*(volatile int*)&abort_flag[par]) break;
             PROF_STAMP(0);  // flag wait
             // lane (row li, k-half hh) of k16-step ks needs k = 16*ks + 8*hh + 4q + 0..3 of producer tile kg:
             // piece (ks*2+q)*64 + lane of that tile -> each wave-load is 1 KiB contiguous
@@ -506,14 +533,14 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             u32x4 raw[KGW][2][2];
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
-                const int kg = wave + 4 * kk;
+                const int kg = wave + NW * kk;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         if (kg < a.n_ct) {
                             const unsigned off = base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024);
-                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
+                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
                         } else {
                             raw[kk][ks][q] = u32x4{0u, 0u, 0u, 0u};
                         }
@@ -570,7 +597,10 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
-                rec[e] = ((red[par][0][o] + red[par][1][o]) + red[par][2][o]) + red[par][3][o];
+                float sum = red[par][0][o];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum = sum + red[par][w][o];
+                rec[e] = sum;
             }
         }
 
@@ -587,6 +617,8 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         }
         f32x4 dwx, spv;
         float du_new[4], dw_new[4];
+        const int pt = tid & 255;
+        const f32x4 al = pconst[0][pt], be = pconst[1][pt], pa = pconst[2][pt], pb = pconst[3][pt], gr = pconst[4][pt];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
@@ -598,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
             const float box = (xs > -0.5f && xs <= 0.5f) ? 1.0f : 0.0f;       // snns.py:34-35
             float du = ds * box + al[e] * du_n[e];
             if (ADAPT) du = du + pa[e] * dw_n[e];
-            dwx[e] = valid ? oma[e] * du : 0.0f;
+            dwx[e] = valid ? (1.0f - al[e]) * du : 0.0f;
             du_new[e] = du;
             dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
             spv[e] = (t > 0) ? sp[e] : 0.0f;  // binary rows only: the s0 term of dV is added by the host
@@ -606,13 +638,13 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         // ---- publish dWx_t first: this thread's 4 values are one 16-byte piece of the tile in fragment
         //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1);
         //      write-through, drain, barrier, tag
-        if (t > 0) {
+        if (pw && t > 0) {
             const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
             const unsigned off = (unsigned)(t % RING) * slot_bytes + rt_off + (unsigned)ct * TILE_BYTES + piece;
             u32x4 rawv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, REC_ST_AUX);
         }
         PROF_STAMP(3);  // pointwise + tile store issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -620,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
         __syncthreads();
         if (tid == 0 && t > 0) {
             gu32* f = (gu32*)a.flags + ((size_t)(t % RING) * a.n_rt_total + rt) * a.n_ct + ct;
-            __hip_atomic_store(f, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f, (unsigned)(T - t), __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
         // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
         if (valid) {
@@ -647,8 +679,9 @@ __global__ __launch_bounds__(256, 1) void rec_bwd_kernel(RecArgs a) {
     if (valid) {
         f32x4 v;
         if (a.t_begin == 0) {  // last chunk of the pass: d u_t / d alpha = (q - u_t) / (1 - alpha)
+            const f32x4 al = pconst[0][tid & 255];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc_al[e] = acc_al[e] / oma[e];
+            for (int e = 0; e < 4; ++e) acc_al[e] = acc_al[e] / (1.0f - al[e]);
         }
         v.x = acc_al[0]; v.y = acc_al[1]; v.z = acc_al[2]; v.w = acc_al[3]; st4(ws, v);
         v.x = du_n[0]; v.y = du_n[1]; v.z = du_n[2]; v.w = du_n[3]; st4(ws + 4 * plane, v);
@@ -716,14 +749,15 @@ size_t bwd_ring_bytes(int Bp, int H) {
 
 template <bool BWD, bool ADAPT>
 int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
-#define SP_LAUNCH(K)                                                                            \
-    if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, K>), dim3(grid), dim3(256), 0, st, a);   \
+    // backward: 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
+#define SP_LAUNCH(K, KB, NWB)                                                                        \
+    if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a); \
     else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, K>), dim3(grid), dim3(256), 0, st, a);
     switch (kgw) {
-        case 1: SP_LAUNCH(1) break;
-        case 2: SP_LAUNCH(2) break;
-        case 4: SP_LAUNCH(4) break;
-        case 8: SP_LAUNCH(8) break;
+        case 1: SP_LAUNCH(1, 1, 4) break;
+        case 2: SP_LAUNCH(2, 1, 8) break;
+        case 4: SP_LAUNCH(4, 2, 8) break;
+        case 8: SP_LAUNCH(8, 4, 8) break;
         default: return SPARCH_EINVAL;
     }
 #undef SP_LAUNCH
