@@ -16,9 +16,9 @@
 //     V = hi + mid + lo (8+8+8 significand bits, exact).  Spikes are 0/1, exact in bf16, so
 //     s@V = s@hi + s@mid + s@lo runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with
 //     exact products and fp32 accumulation: same accuracy class as an fp32 fmaf chain at 3/16
-//     of its cost.  In the backward dWx is split as well (x = t1 + t2 + t3 exactly) and the seven
-//     largest cross terms (t1*hi, t1*mid, t2*hi, t1*lo, t3*hi, t2*mid, t3*mid; the dropped ones
-//     are <= 2^-23 relative) are accumulated: fp32-faithful at 7/16 of the fp32 MFMA cost;
+//     of its cost.  In the backward dWx is split as well (x = t1 + t2 + t3 exactly) and the six
+//     largest cross terms (t1*hi, t1*mid, t2*hi, t1*lo, t3*hi, t2*mid; the dropped ones are
+//     <= 2^-25 relative each) are accumulated: fp32-faithful at 6/16 of the fp32 MFMA cost;
 //   * the 32 workgroups of one batch tile exchange the step's output every step:
 //       forward  — spikes, bit-packed, as 8-byte {tag = t+1, 32 spike bits} granules written
 //                  with one agent-scope (sc1, write-through) store each and polled with sc1
@@ -140,12 +140,12 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
 }
 
 // V (or V^T) slice -> registers: per k-group, 2 k16-steps x 3 planes of 8 bf16 (4 VGPRs) each
-template <int KGW>
+template <int KGW, int NW>
 __device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4* __restrict__ vpack, int ct,
                                             int nkg, int wave, int lane) {
 #pragma unroll
     for (int kk = 0; kk < KGW; ++kk) {
-        const int kg = wave + 4 * kk;
+        const int kg = wave + NW * kk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -155,9 +155,12 @@ __device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4*
 }
 
 // ------------------------------------------------------------------------------ forward
-template <bool ADAPT, int KGW>
-__global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][4][RT * RED_LD];
+// NW waves per workgroup, each taking the k-groups kg = wave + NW*kk of the contraction (partial tiles
+// summed through LDS); NW = 8 puts two waves on each SIMD so that one's LUT reads / poll latency sit
+// under the other's MFMAs.  Pointwise update, publish and stores stay on the first 256 threads.
+template <bool ADAPT, int KGW, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
     __shared__ int abort_flag[2];
     __shared__ unsigned cnt_lds[2][CT];
@@ -171,15 +174,16 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
 
     // element ownership for the pointwise update: row r, 4 columns
-    const int r = tid >> 3, cq = tid & 7;
+    const bool pw = tid < 256;
+    const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
-    const bool valid = bp < a.Bp && col < H;
+    const bool valid = pw && bp < a.Bp && col < H;
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
     u32x4 vb[KGW][2][3];
-    load_vslice<KGW>(vb, a.vpack, ct, a.nkg, wave, lane);
-    {
+    load_vslice<KGW, NW>(vb, a.vpack, ct, a.nkg, wave, lane);
+    if (pw) {
         u32x4 e;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         const int tt = d ? (T - 1 - t) : t;
         return a.Wx + ((size_t)b * T + tt) * H + colc;
     };
-    f32x4 x_next = ld4(wx_ptr(a.t_begin));
+    f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
+    if (pw) x_next = ld4(wx_ptr(a.t_begin));
     // Bulk HBM stores of a step are held back (12 VGPRs) and issued only after the NEXT step's poll loads:
     // vmcnt retires in order and counts stores, so stores (and the Wx prefetch) issued ahead of the poll
     // would put their HBM latency in front of the sweep.  Issued behind it they retire under the MFMA phase.
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         if (t == 0) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
-            if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
+            if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
         } else {
             // ---- gather the 32 x H spike bits of step t-1 (tag == t) for this wave's k-groups
             const gu64* base = (const gu64*)a.chan + ((size_t)(t - 1) * a.n_rt_total + rt) * a.n_ct * 32;
@@ -262,13 +267,13 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
                 // trips, ~5.5k cycles per step — the largest single cost of the first versions.)
 #pragma unroll
                 for (int kk = 0; kk < KGW; ++kk) {
-                    const int kgc = min(wave + 4 * kk, a.n_ct - 1);
+                    const int kgc = min(wave + NW * kk, a.n_ct - 1);
                     gran[kk] = __hip_atomic_load(base + (size_t)kgc * 32 + li, __ATOMIC_RELAXED, REC_LD_SCOPE);
                 }
                 unsigned bad = 0;
 #pragma unroll
                 for (int kk = 0; kk < KGW; ++kk) {
-                    const unsigned m = (wave + 4 * kk < a.n_ct) ? 0xFFFFFFFFu : 0u;
+                    const unsigned m = (wave + NW * kk < a.n_ct) ? 0xFFFFFFFFu : 0u;
                     bad |= ((unsigned)(gran[kk] >> 32) ^ (unsigned)t) & m;
                 }
                 if (__all(bad == 0)) break;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             }
             PROF_STAMP(0);  // poll wait
             flush_pending();
-            if (t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
+            if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
             // ---- s_{t-1} @ V on the bf16 MFMA: spikes expanded through the LDS table (lane
             //      (row li, k-half hh) takes byte 2*ks + hh of its row's 32-bit word)
             u32x4 af[KGW][2];
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
             for (int kk = 0; kk < KGW; ++kk) {
                 // k-groups beyond H (padding of the register layout) contribute zero spikes; keeping the whole
                 // section free of branches lets the scheduler interleave LUT reads with the MFMA chain
-                const unsigned wbits = (wave + 4 * kk < a.n_ct) ? (unsigned)gran[kk] : 0u;
+                const unsigned wbits = (wave + NW * kk < a.n_ct) ? (unsigned)gran[kk] : 0u;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) af[kk][ks] = lut[(wbits >> (16 * ks + 8 * hh)) & 0xFFu];
             }
@@ -317,7 +322,10 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
-                rec[e] = ((red[t & 1][0][o] + red[t & 1][1][o]) + red[t & 1][2][o]) + red[t & 1][3][o];
+                float sum = red[t & 1][0][o];
+#pragma unroll
+                for (int w_ = 1; w_ < NW; ++w_) sum = sum + red[t & 1][w_][o];
+                rec[e] = sum;
             }
         }
 
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void rec_fwd_kernel(RecArgs a) {
         word |= __shfl_xor(word, 1);
         word |= __shfl_xor(word, 2);
         word |= __shfl_xor(word, 4);
-        if (cq == 0 && t + 1 < T) {
+        if (pw && cq == 0 && t + 1 < T) {
             gu64* slot = (gu64*)a.chan + (((size_t)t * a.n_rt_total + rt) * a.n_ct + ct) * 32 + r;
             __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
@@ -571,8 +579,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                                 p3[2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
                             }
                         const u32x4 vl = vlo[wave][kk][ks][lane];
-                        // seven largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first
-                        acc = mfma_bf16(p3, vb[kk][ks][1], acc);  // t3*mid
+                        // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first.  Dropped:
+                        // t3*mid, t2*lo (<= 2^-25 relative each: |t3| < 2^-16 |x| after two 8-bit truncations,
+                        // |V_mid| <= 2^-9 |V|) and t3*lo — the same cut as the dense 6-term GEMM.
                         acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
                         acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
                         acc = mfma_bf16(p1, vl, acc);             // t1*lo
@@ -749,10 +758,10 @@ size_t bwd_ring_bytes(int Bp, int H) {
 
 template <bool BWD, bool ADAPT>
 int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
-    // backward: 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
+    // 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
 #define SP_LAUNCH(K, KB, NWB)                                                                        \
     if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a); \
-    else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, K>), dim3(grid), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a);
     switch (kgw) {
         case 1: SP_LAUNCH(1, 1, 4) break;
         case 2: SP_LAUNCH(2, 1, 8) break;
