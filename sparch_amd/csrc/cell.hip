@@ -293,8 +293,16 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
         }
         __builtin_amdgcn_wave_barrier();
         // lane = class: out += softmax(u_t) in time order                 // snns.py:823
-        if (act)
-            for (int tl = 0; tl < len; ++tl) acc = acc + us[tl * CS + cc];
+        if (act) {
+            for (int t0 = 0; t0 < len; t0 += RU) {  // reads first (independent), then the ordered adds
+                float pv[RU];
+#pragma unroll
+                for (int j = 0; j < RU; ++j) pv[j] = (t0 + j < len) ? us[(t0 + j) * CS + cc] : 0.f;
+#pragma unroll
+                for (int j = 0; j < RU; ++j)
+                    if (t0 + j < len) acc = acc + pv[j];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (act) out[(size_t)b * C + cc] = acc;
@@ -361,11 +369,14 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int B, int T, int C, co
                 const int t = c0 + t0 - j;
                 uc[j] = t >= 0 ? ur[(size_t)t * C] : (t == -1 ? u0[(size_t)b * C + cc] : 0.f);
             }
+            float ev[RU];
+#pragma unroll
+            for (int j = 0; j < RU; ++j) ev[j] = (t0 - j >= 0) ? us[(t0 - j) * CS + cc] : 0.f;
 #pragma unroll
             for (int j = 0; j < RU; ++j) {
                 const int tl = t0 - j;
                 if (tl < 0) break;
-                du = al * du + us[tl * CS + cc];
+                du = al * du + ev[j];
                 if (act) dWx[((size_t)b * T + c0 + tl) * C + cc] = oma * du;
                 acc += du * (uc[j + 1] - uc[j]);
             }

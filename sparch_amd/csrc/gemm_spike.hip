@@ -244,13 +244,17 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // traffic at full MFMA rate against a 128 B/clk LDS — the measured limiter (ablation: dropping the
 // fragment reads took the TN kernel from 0.50 to 0.22 ms).  The spike-operand kernels therefore put 4 tiles
 // on the single-plane (spike) side and 2 on the three-plane side: 10 reads per 24 MFMAs.
-template <int MODE, bool FAST> struct Shape {
+// BIG (TN spike kernels only): 256 x 256 workgroup tile.  What bounds these kernels beside the matrix pipe is
+// the CU's fill rate from L2 / Infinity Cache (~70 / ~33 GB/s per CU measured, MI355X_MICROARCH.md), and a
+// 256 x 128 tile pulls 48 KB per 48 MFMAs per SIMD; 256 x 256 pulls 64 KB per 96.  (The NT images do not fit
+// two LDS stages at that size, and there the dense operand is the small, L2-resident weight matrix anyway.)
+template <int MODE, bool FAST, bool BIG = false> struct Shape {
     // FAST: 8 waves (2 per SIMD, so that one wave's vector-memory issue stalls and barrier waits are
     // covered by the other's MFMAs) in one workgroup per CU; general kernel: 4 waves, 2 workgroups per CU.
     static constexpr int WM = FAST ? (MODE == 1 ? 4 : 2) : 2;   // waves along M
     static constexpr int WN = FAST ? (MODE == 1 ? 2 : 4) : 2;   // waves along N
-    static constexpr int WI = FAST ? (MODE == 0 ? 4 : (MODE == 1 ? 1 : 2)) : 2;  // 32-row MFMA tiles per wave
-    static constexpr int WJ = FAST ? (MODE == 1 ? 4 : 1) : 2;
+    static constexpr int WI = FAST ? (MODE == 0 ? 4 : (MODE == 1 ? (BIG ? 2 : 1) : 2)) : 2;  // 32-row MFMA tiles per wave
+    static constexpr int WJ = FAST ? (MODE == 1 ? 4 : (MODE == 0 && BIG ? 2 : 1)) : 2;
     static constexpr int BM = 32 * WI * WM, BN = 32 * WJ * WN;
     static constexpr int NT = 64 * WM * WN;
     // workgroups per CU the register / LDS budget is set for
@@ -261,8 +265,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned short dyn_lds[];
 
 template <bool A_KM, bool B_KM, int MODE, bool FAST>
 constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of both operand tiles)
-    return (MODE == 0 ? 1 : 3) * plane_elems<A_KM, Shape<MODE, FAST>::BM>() +
-           (MODE == 1 ? 1 : 3) * plane_elems<B_KM, Shape<MODE, FAST>::BN>();
+    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
+    return (MODE == 0 ? 1 : 3) * plane_elems<A_KM, S::BM>() + (MODE == 1 ? 1 : 3) * plane_elems<B_KM, S::BN>();
 }
 
 // FAST: one workgroup per CU (one wave per SIMD, up to 512 registers), TWO LDS stages, and the whole
@@ -275,7 +279,7 @@ constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of 
 // !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
 __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
-    using S = Shape<MODE, FAST>;
+    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
     constexpr int WI = S::WI, WJ = S::WJ, WN = S::WN, BM = S::BM, BN = S::BN, NT = S::NT;
@@ -568,7 +572,8 @@ int target_wgs(int occ) {
 }
 template <int MODE>
 int choose_splits(int M, int N, int K) {
-    const int tiles = cdiv(M, Shape<MODE, true>::BM) * cdiv(N, Shape<MODE, true>::BN);
+    using S = Shape<MODE, true, MODE != 2>;  // TN products only
+    const int tiles = cdiv(M, S::BM) * cdiv(N, S::BN);
     const int kt = cdiv(K, BK);
     int s = target_wgs(1) / tiles;  // the pipelined kernel runs one workgroup per CU
     if (s > kt / 8) s = kt / 8;
@@ -577,7 +582,8 @@ int choose_splits(int M, int N, int K) {
 
 template <bool A_KM, bool B_KM, int MODE, int EPI>
 bool fast_ok(const SArgs& g) {
-    constexpr int BM = Shape<MODE, true>::BM, BN = Shape<MODE, true>::BN;
+    using S = Shape<MODE, true, A_KM && B_KM && MODE != 2>;
+    constexpr int BM = S::BM, BN = S::BN;
     // the shifted-edge-tile kernel needs whole tiles to exist, 16-byte rows, and (for the BatchNorm
     // statistics, which are kept per 128-row block) no partial row tile
     return g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % 4 == 0) && (!B_KM || g.N % 4 == 0) &&
@@ -587,7 +593,8 @@ bool fast_ok(const SArgs& g) {
 
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
-    const int wgs = cdiv(g.M, Shape<MODE, FAST>::BM) * cdiv(g.N, Shape<MODE, FAST>::BN) * splits;
+    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
+    const int wgs = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
     auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
