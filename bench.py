@@ -159,7 +159,7 @@ def main():
     net = sparch_amd.SNN((B, None, C), w["layer_sizes"], neuron_type=w["neuron_type"], dropout=w["pdrop"],
                          normalization="batchnorm").to(dev)
     net.train()
-    opt = torch.optim.Adam(net.parameters(), 1e-2)  # exp.py:89
+    opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)  # exp.py:89 (same arithmetic, one launch: SURVEY f-2)
     loss_fn = torch.nn.CrossEntropyLoss()           # exp.py:100
     reducer = dp.GradAllReducer(net) if world > 1 else None
     g = torch.Generator().manual_seed(4321 + rank)

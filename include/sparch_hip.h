@@ -269,6 +269,16 @@ int sparch_bin_events(long long n_events, const float* times, const int* units,
                       const long long* sample_offsets, int n_samples, int nb_steps, int nb_units,
                       double max_time, float* out, uint32_t* n_dropped, void* stream);
 
+/* ---- f-2: optimizer step on the device (replaces torch.optim.Adam.step, exp.py:89, 377) ----------
+ * One launch for the whole parameter list; arithmetic identical, operation by operation, to
+ * torch.optim.Adam's default path (see optim.hip).  `params`, `grads`, `exp_avg`, `exp_avg_sq` are HOST
+ * arrays of n_tensors DEVICE pointers, `numel` a host array of element counts.
+ * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t): formed by the caller in double precision. */
+int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
+                     float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                     float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
+                     float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

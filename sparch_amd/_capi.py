@@ -72,6 +72,7 @@ PROTOTYPES = {
     "sparch_fbank_frames": (c_int, [c_int]),
     "sparch_fbank_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
     "sparch_bin_events": (c_int, [c_longlong, P, P, P, c_int, c_int, c_int, c_double, P, P, P]),
+    "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 
 

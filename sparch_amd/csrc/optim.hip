@@ -1,0 +1,89 @@
+// f-2: Adam step for a whole parameter list in ONE launch (the reference calls torch.optim.Adam,
+// exp.py:89, 377: ~30 small kernels per step on the device).
+//
+// Same arithmetic, operation by operation, as torch.optim.Adam's default (foreach, non-amsgrad) path:
+//     m  = m + (g - m) * (1 - beta1)                         (Tensor.lerp_)
+//     v  = v * beta2 + (g * g) * (1 - beta2)                 (mul_, addcmul_)
+//     d  = sqrt(v) / sqrt(1 - beta2^t) + eps
+//     p  = p + (m / d) * (-lr / (1 - beta1^t))               (addcdiv_)
+// with the scalar factors formed on the host in double precision as Python does and rounded to fp32
+// once.  Built with -ffp-contract=off: no fused multiply-adds the reference's separate kernels do not have.
+// The tensor table travels in the kernel argument (no device-side descriptor to keep coherent with
+// autograd's fresh .grad tensors each step).
+#include "common.h"
+
+namespace {
+
+constexpr int ADAM_MAX = 24;       // tensors per launch (kernel-argument budget)
+constexpr int ADAM_CHUNK = 4096;   // elements per workgroup
+
+struct AdamBatch {
+    float* p[ADAM_MAX];
+    const float* g[ADAM_MAX];
+    float* m[ADAM_MAX];
+    float* v[ADAM_MAX];
+    long long first_blk[ADAM_MAX + 1];  // prefix sum of ceil(n / ADAM_CHUNK)
+    long long n[ADAM_MAX];
+    int count;
+    float step_size, beta1, beta2, bc2_sqrt, eps, weight_decay;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
+    int ti = 0;
+    while (ti + 1 < a.count && (long long)blockIdx.x >= a.first_blk[ti + 1]) ++ti;  // uniform, <= 24 steps
+    const long long base = ((long long)blockIdx.x - a.first_blk[ti]) * ADAM_CHUNK;
+    const long long n = a.n[ti];
+    float* __restrict__ p = a.p[ti];
+    const float* __restrict__ g = a.g[ti];
+    float* __restrict__ m = a.m[ti];
+    float* __restrict__ v = a.v[ti];
+    const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
+#pragma unroll 4
+    for (int j = 0; j < ADAM_CHUNK / 256; ++j) {
+        const long long i = base + (long long)j * 256 + threadIdx.x;
+        if (i >= n) break;
+        float gi = g[i];
+        const float pi = p[i];
+        if (a.weight_decay != 0.0f) gi = gi + pi * a.weight_decay;
+        const float mi = m[i] + (gi - m[i]) * w1;
+        const float vi = v[i] * a.beta2 + (gi * gi) * w2;
+        const float d = sqrtf(vi) / a.bc2_sqrt + a.eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi + (mi / d) * (-a.step_size);
+    }
+}
+
+}  // namespace
+
+extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
+                                float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
+                                float weight_decay, void* stream) {
+    SPARCH_ENTER();
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
+        return SPARCH_EINVAL;
+    if (!(bc2_sqrt > 0.0f)) return SPARCH_EINVAL;
+    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX) {
+        AdamBatch a{};
+        a.count = 0;
+        long long blk = 0;
+        for (int t = t0; t < n_tensors && a.count < ADAM_MAX; ++t) {
+            if (numel[t] < 0 || (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])))
+                return SPARCH_EINVAL;
+            if (numel[t] == 0) continue;
+            const int c = a.count++;
+            a.p[c] = params[t]; a.g[c] = grads[t]; a.m[c] = exp_avg[t]; a.v[c] = exp_avg_sq[t];
+            a.n[c] = numel[t];
+            a.first_blk[c] = blk;
+            blk += (numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+        }
+        a.first_blk[a.count] = blk;
+        if (a.count == 0) continue;
+        a.step_size = step_size; a.beta1 = beta1; a.beta2 = beta2; a.bc2_sqrt = bc2_sqrt; a.eps = eps;
+        a.weight_decay = weight_decay;
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, a);
+        SPARCH_CHECK_LAUNCH();
+    }
+    return SPARCH_OK;
+}

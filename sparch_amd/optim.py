@@ -1,0 +1,79 @@
+"""
+Optimizer step on the device in one launch.
+
+`Adam` is a drop-in for the reference's `torch.optim.Adam(net.parameters(), lr)` (exp.py:89): same
+constructor arguments, same `param_groups` (so `ReduceLROnPlateau`, exp.py:91-98, drives `lr` unchanged),
+same `state_dict()` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter) — a checkpoint of one loads into
+the other.  The arithmetic is torch's default Adam path operation by operation (csrc/optim.hip); `step`
+needs no host round trip.  amsgrad / maximize / capturable variants are not part of the reference's use and
+raise.
+"""
+import ctypes
+import math
+
+import torch
+
+from ._capi import check, lib
+from .functional import _stream
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if not 0.0 <= lr:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not 0.0 <= eps:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 0: {betas[0]}")
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 1: {betas[1]}")
+        if not 0.0 <= weight_decay:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        if amsgrad:
+            raise NotImplementedError("sparch_amd.optim.Adam: amsgrad is not implemented (the reference does not use it)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            beta1, beta2 = group["betas"]
+            steps = set()
+            for p in ps:
+                if p.dtype != torch.float32 or not p.is_cuda or p.grad.is_sparse:
+                    raise RuntimeError("sparch_amd.optim.Adam: float32 dense parameters on the GPU only")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)  # host scalar, as torch.optim.Adam keeps it
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                steps.add(float(st["step"]))
+            # parameters that joined at different times step separately (never the case in the reference's use)
+            for t in sorted(steps):
+                sel = [p for p in ps if float(self.state[p]["step"]) == t]
+                bc1 = 1.0 - beta1 ** t
+                bc2 = 1.0 - beta2 ** t
+                self._launch(sel, group["lr"] / bc1, beta1, beta2, math.sqrt(bc2), group["eps"], group["weight_decay"])
+        return loss
+
+    def _launch(self, ps, step_size, beta1, beta2, bc2_sqrt, eps, weight_decay):
+        n = len(ps)
+        arr = ctypes.c_void_p * n
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+        for p in ps:
+            if not p.is_contiguous():
+                raise RuntimeError("sparch_amd.optim.Adam: parameters must be contiguous")
+        a_p = arr(*[p.data_ptr() for p in ps])
+        a_g = arr(*[g.data_ptr() for g in grads])
+        a_m = arr(*[self.state[p]["exp_avg"].data_ptr() for p in ps])
+        a_v = arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps])
+        a_n = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+        check(lib.sparch_adam_step(n, a_p, a_g, a_m, a_v, a_n, float(step_size), float(beta1), float(beta2),
+                                   float(bc2_sqrt), float(eps), float(weight_decay), _stream()), "sparch_adam_step")
