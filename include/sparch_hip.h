@@ -86,6 +86,18 @@ int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int lda, float
                          float* colstat_ws, void* stream);
 size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K);
 
+/* The same products with the spike operand given as a bf16 PLANE (uint16 bit patterns, entries 0 or
+ * 0x3F80 = 1.0; any bf16 value is taken as is): the cell kernels write this plane next to their fp32
+ * output (s16 below), and the GEMMs then pull half the operand bytes.  lda / ldb of the plane are in
+ * elements.  spike16_tn: the operand named by spike_side is the uint16 plane, the other one fp32;
+ * workspace as sparch_gemm_spike_tn_workspace_bytes.                                               */
+int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
+                           const float* B, int ldb, float* C, int ldc, const float* bias,
+                           float* colstat_ws, void* stream);
+int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           int spike_side, float scale, float* C, int ldc, int zero_diag,
+                           int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* Dense x dense products on the same exact-split machinery: BOTH fp32 operands are split into three
  * bf16 planes and the six cross terms >= 2^-16 relative are accumulated in fp32 (dropped terms
  * <= 2^-24): fp32-faithful results at 6/16 of the fp32-MFMA cost.  Same argument meaning as
@@ -163,6 +175,8 @@ int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const fl
  *   u0,w0,s0 (Bp,H)  random initial states drawn by the host in the reference's order.
  *   s_out   (B,T,H*dirs)  post-dropout output; direction d lands in features [d*H,(d+1)*H)
  *           at its ORIGINAL time index (un-flipped), as snns.py:272-275.
+ *   s16_out (B,T,H*dirs)  the same spikes as a bf16 plane (uint16 bit patterns: 0x3F80 where
+ *           s_out != 0, else 0) for sparch_gemm_spike16_*; NULL => not written.
  *   u_save, w_save (Bp,T,H) in cell time order; needed by the backward (NULL => not saved).
  *   spike_count (H*dirs) uint32: number of spikes surviving dropout per output feature;
  *           firing rate = count * keep_scale / (B*T)  (snns.py:174 after 278).
@@ -174,7 +188,7 @@ int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
                     const float* scale, const float* shift, const float* alpha,
                     const float* beta, const float* a, const float* b, const float* u0,
                     const float* w0, const float* s0, float theta, float p_drop,
-                    uint64_t seed, float* s_out, float* u_save, float* w_save,
+                    uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
                     uint32_t* spike_count, void* stream);
 
 /* g_out (B,T,H*dirs) upstream gradient of s_out; g_rate (H*dirs) upstream gradient of the
@@ -207,18 +221,19 @@ int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx
                         const float* beta, const float* a, const float* b,
                         const float* vpack, const float* rec0, const float* u0,
                         const float* w0, const float* s0, float theta, float p_drop,
-                        uint64_t seed, float* s_out, float* u_save, float* w_save,
-                        uint32_t* spike_count, void* chan, size_t chan_bytes,
+                        uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save,
+                        float* w_save, uint32_t* spike_count, void* chan, size_t chan_bytes,
                         uint32_t* status, int steps_per_launch, void* stream);
-/* Backward: dWx doubles as the hand-off buffer (each step's 32x32 tile is published
- * write-through and flagged in `chan`).  s_prev (Bp,T,H) receives s_{t-1} (s0 at t=0)
- * for the dV = s_prev^T * dWx GEMM.                                                   */
+/* Backward: each step's 32x32 dWx tile is handed to the other workgroups through `chan`.
+ * s_prev16 (Bp,T,H) receives s_{t-1} as a bf16 plane (binary for t >= 1, a zero row at
+ * t = 0: the non-binary s0 term is added by the caller) for dV = s_prev^T * dWx
+ * (sparch_gemm_spike16_tn, spike_side 0).                                             */
 int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
                         const float* g_rate, const float* u_save, const float* w_save,
                         const float* alpha, const float* beta, const float* a,
                         const float* b, const float* vpack_t, const float* u0,
                         const float* w0, const float* s0, float theta, float p_drop,
-                        uint64_t seed, float* dWx, float* s_prev, float* dparam_ws,
+                        uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
                         void* chan, size_t chan_bytes, uint32_t* status,
                         int steps_per_launch, void* stream);
 

@@ -4,7 +4,7 @@
 static thread_local int g_last_hip_error = 0;
 void sparch_note_hip_error(int e) { g_last_hip_error = e; }
 
-extern "C" int sparch_abi_version(void) { return 1; }
+extern "C" int sparch_abi_version(void) { return 2; }  // 2: bf16 spike planes (s16_out, s_prev16, spike16 GEMMs), adam
 
 extern "C" const char* sparch_last_hip_error(void) {
     return hipGetErrorString((hipError_t)g_last_hip_error);

@@ -29,7 +29,7 @@ struct CellArgs {
     const float* alpha; const float* beta; const float* a; const float* b;
     const float* u0; const float* w0; const float* s0;
     float theta, p_drop, inv_keep; uint64_t seed;
-    float* s_out; float* u_save; float* w_save; uint32_t* spike_count;
+    float* s_out; uint16_t* s16_out; float* u_save; float* w_save; uint32_t* spike_count;
     // backward
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; float* dparam_ws;
@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
             stv<VEC>(c.s_out + o, so);
+            if (c.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) c.s16_out[o + e] = so[e] != 0.0f ? (uint16_t)0x3F80 : (uint16_t)0;
+            }
             if (c.u_save) stv<VEC>(c.u_save + ((size_t)bp * T + t) * H + h, u);
             if (ADAPT && c.w_save) stv<VEC>(c.w_save + ((size_t)bp * T + t) * H + h, w);
         }
@@ -417,7 +421,7 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
                                const float* scale, const float* shift, const float* alpha,
                                const float* beta, const float* a, const float* b, const float* u0,
                                const float* w0, const float* s0, float theta, float p_drop,
-                               uint64_t seed, float* s_out, float* u_save, float* w_save,
+                               uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
                                uint32_t* spike_count, void* stream) {
     SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
@@ -434,7 +438,7 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
     c.alpha = alpha; c.beta = beta; c.a = a; c.b = b;
     c.u0 = u0; c.w0 = w0; c.s0 = s0;
     c.theta = theta; c.p_drop = p_drop; c.inv_keep = 1.0f / (1.0f - p_drop); c.seed = seed;
-    c.s_out = s_out; c.u_save = u_save; c.w_save = w_save; c.spike_count = spike_count;
+    c.s_out = s_out; c.s16_out = s16_out; c.u_save = u_save; c.w_save = w_save; c.spike_count = spike_count;
     return adapt ? launch_cell<true>(false, c, (hipStream_t)stream)
                  : launch_cell<false>(false, c, (hipStream_t)stream);
 }

@@ -140,13 +140,53 @@ __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const f
     }
     out = v;
 }
+// ---- the same for a spike operand held as a bf16 plane (0 / 1.0; SURVEY f: the producers write it next to
+// their fp32 output): 8 elements per 16-byte piece, half the bytes through the CU's L1 fill path — which,
+// beside the matrix pipe, is what bounds these kernels.
 template <bool KM, int ROWS, int NT>
-__device__ __forceinline__ void stage_load(f32x4 (&r)[ROWS * 8 / NT], const float* __restrict__ P, int ld, int row0,
-                                           int rows, int k0, int kend, int vec, int tid) {
+__device__ __forceinline__ void load_piece16(f32x4& out, int p, bool fast, const unsigned short* __restrict__ P,
+                                             int ld, int row0, int rows, int k0, int kend, int vec, int tid) {
+    constexpr int RQ = ROWS / 8;  // pieces per k row of a KM tile
+    const int f = tid + NT * p;
+    int row, k;
+    if constexpr (!KM) { row = row0 + (f >> 2); k = k0 + ((f & 3) << 3); }
+    else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 3); }
+    const unsigned short* q = KM ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
+    if (fast) { out = *reinterpret_cast<const f32x4*>(q); return; }
+    u32x4 v = {0u, 0u, 0u, 0u};
+    const bool outer_ok = KM ? (k < kend) : (row < rows);
+    const int inner = KM ? row : k, inner_end = KM ? rows : kend;
+    if (outer_ok) {
+        if (vec && inner + 7 < inner_end) v = *reinterpret_cast<const u32x4*>(q);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (inner + e < inner_end) v[e >> 1] |= (unsigned)q[e] << (16 * (e & 1));
+        }
+    }
+    out = __builtin_bit_cast(f32x4, v);
+}
+template <bool KM, int ROWS, int NT>
+__device__ __forceinline__ void store_piece16(const f32x4& r, int p, unsigned short* __restrict__ S, int tid) {
+    constexpr int RQ = ROWS / 8;
+    const int f = tid + NT * p;
+    int off;  // bf16 elements, 16-byte aligned (80-byte KC rows, 16-byte multiples for KM rows)
+    if constexpr (!KM) off = (f >> 2) * KC_ROW + ((f & 3) << 3);
+    else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 3);
+    *reinterpret_cast<f32x4*>(S + off) = r;
+}
+template <bool KM, int ROWS, int NT, bool H16 = false>
+__device__ __forceinline__ void stage_load(f32x4 (&r)[ROWS * (H16 ? 4 : 8) / NT], const float* __restrict__ P, int ld,
+                                           int row0, int rows, int k0, int kend, int vec, int tid) {
     const bool fast = tile_is_full<KM, ROWS>(row0, rows, k0, kend, vec);
 #pragma unroll
-    for (int p = 0; p < ROWS * 8 / NT; ++p)
-        load_piece<KM, ROWS, NT>(r[p], p, fast, P, ld, row0, rows, k0, kend, vec, tid);
+    for (int p = 0; p < ROWS * (H16 ? 4 : 8) / NT; ++p) {
+        if constexpr (H16)
+            load_piece16<KM, ROWS, NT>(r[p], p, fast, reinterpret_cast<const unsigned short*>(P), ld, row0, rows, k0,
+                                       kend, vec, tid);
+        else
+            load_piece<KM, ROWS, NT>(r[p], p, fast, P, ld, row0, rows, k0, kend, vec, tid);
+    }
 }
 
 // ---- registers -> LDS with conversion.  SPIKE: one plane of 0/1; else three planes hi/mid/lo.
@@ -277,8 +317,9 @@ constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of 
 // phase, barrier — the matrix pipe was busy 47 % of the time: neither workgroup's latency chain was
 // short enough for two to cover each other.)
 // !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16>
 __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
+    static_assert(!S16 || MODE != 2, "a bf16 plane is a spike operand");
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
@@ -319,19 +360,31 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NPA = BM * 8 / NT, NPB = BN * 8 / NT;  // 16-byte pieces per thread and tile
+    constexpr bool A16 = S16 && SPIKE_A, B16 = S16 && SPIKE_B;     // operand arrives as a bf16 plane
+    constexpr int NPA = BM * (A16 ? 4 : 8) / NT, NPB = BN * (B16 ? 4 : 8) / NT;  // 16-byte pieces per thread and tile
     f32x4 ra[NPA], rb[NPB];
 
     // registers -> LDS stage at `st` (piece q of the NPA + NPB pieces a thread owns)
     auto convert_piece = [&](int q, unsigned short* st) __attribute__((always_inline)) {
-        if (q < NPA) store_piece<A_KM, BM, NT, SPIKE_A, MODE != 2>(ra[q], q, st, tid, g.e_exact);
-        else if (q < NPA + NPB)
-            store_piece<B_KM, BN, NT, SPIKE_B, MODE != 2>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid, g.e_exact);
+        if (q < NPA) {
+            if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
+            else store_piece<A_KM, BM, NT, SPIKE_A, MODE != 2>(ra[q], q, st, tid, g.e_exact);
+        } else if (q < NPA + NPB) {
+            if constexpr (B16) store_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
+            else store_piece<B_KM, BN, NT, SPIKE_B, MODE != 2>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid, g.e_exact);
+        }
     };
     // global -> registers, full in-range tile at K offset k (FAST only)
     auto fetch_piece = [&](int q, int k) __attribute__((always_inline)) {
-        if (q < NPA) load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
-        else if (q < NPA + NPB) load_piece<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
+        if (q < NPA) {
+            if constexpr (A16)
+                load_piece16<A_KM, BM, NT>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
+            else load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
+        } else if (q < NPA + NPB) {
+            if constexpr (B16)
+                load_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, reinterpret_cast<const unsigned short*>(g.B), g.ldb, n0, g.N, k, k_end, 1, tid);
+            else load_piece<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
+        }
     };
 
     // The MFMA phase of one K tile held in the LDS stage `cur`.  Fragment reads run one group AHEAD of the
@@ -458,8 +511,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         }
         const int k_tail = k_begin + nt * BK;
         if (k_tail < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
-            stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
-            stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
+            stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
+            stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
 #pragma unroll
             for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
             __syncthreads();
@@ -467,15 +520,15 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             __syncthreads();
         }
     } else {
-        stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
-        stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
+        stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid);
+        stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
             for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
             __syncthreads();
             if (k0 + BK < k_end) {
-                stage_load<A_KM, BM, NT>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
-                stage_load<B_KM, BN, NT>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
+                stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
+                stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
             }
             mfma_phase(lds, no_side);
             __syncthreads();
@@ -580,23 +633,24 @@ int choose_splits(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16>
 bool fast_ok(const SArgs& g) {
     using S = Shape<MODE, true, A_KM && B_KM && MODE != 2>;
     constexpr int BM = S::BM, BN = S::BN;
+    constexpr int QA = (S16 && MODE == 0) ? 8 : 4, QB = (S16 && MODE == 1) ? 8 : 4;  // elements per 16 bytes
     // the shifted-edge-tile kernel needs whole tiles to exist, 16-byte rows, and (for the BatchNorm
     // statistics, which are kept per 128-row block) no partial row tile
-    return g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % 4 == 0) && (!B_KM || g.N % 4 == 0) &&
+    return g.a_vec && g.b_vec && g.M >= BM && g.N >= BN && (!A_KM || g.M % QA == 0) && (!B_KM || g.N % QB == 0) &&
            (!(EPI & EPI_STATS) || g.M % BM == 0) && g.k_per_split % BK == 0 &&
            g.k_per_split >= 8 * BK;  // a short K range never fills the pipeline: general kernel, 2 workgroups per CU
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     const int wgs = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
-    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST>;
+    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
@@ -605,10 +659,10 @@ int launch_variant(SArgs& g, int splits, hipStream_t st) {
     return SPARCH_OK;
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16 = false>
 int launch(SArgs& g, int splits, hipStream_t st) {
-    if (fast_ok<A_KM, B_KM, MODE, EPI>(g)) return launch_variant<A_KM, B_KM, MODE, EPI, true>(g, splits, st);
-    return launch_variant<A_KM, B_KM, MODE, EPI, false>(g, splits, st);
+    if (fast_ok<A_KM, B_KM, MODE, EPI, S16>(g)) return launch_variant<A_KM, B_KM, MODE, EPI, true, S16>(g, splits, st);
+    return launch_variant<A_KM, B_KM, MODE, EPI, false, S16>(g, splits, st);
 }
 
 }  // namespace
@@ -648,6 +702,52 @@ extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda
     g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
     int rc = spike_side == 0 ? launch<true, true, 0, EPI_NONE>(g, splits, st)
                              : launch<true, true, 1, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+// ---- the spike operand as a bf16 plane (entries 0 / 1.0, written by the cell kernels next to their fp32
+// output): same products, half the operand bytes
+extern "C" int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
+                                      const float* B, int ldb, float* C, int ldc, const float* bias,
+                                      float* colstat_ws, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A_spk16 || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = reinterpret_cast<const float*>(A_spk16); g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = scale;
+    g.a_vec = aligned16(A_spk16) && (lda % 8 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (colstat_ws) return launch<false, false, 0, EPI_BIAS | EPI_STATS, true>(g, 1, st);
+    if (bias) return launch<false, false, 0, EPI_BIAS, true>(g, 1, st);
+    return launch<false, false, 0, EPI_NONE, true>(g, 1, st);
+}
+
+extern "C" int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                      int spike_side, float scale, float* C, int ldc, int zero_diag,
+                                      int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
+    if (spike_side != 0 && spike_side != 1) return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = spike_side == 0 ? choose_splits<0>(M, N, K) : choose_splits<1>(M, N, K);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
+    SArgs g{};
+    g.A = static_cast<const float*>(A); g.B = static_cast<const float*>(B);
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.scale = scale;
+    g.a_vec = aligned16(A) && (lda % (spike_side == 0 ? 8 : 4) == 0);
+    g.b_vec = aligned16(B) && (ldb % (spike_side == 1 ? 8 : 4) == 0);
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    int rc = spike_side == 0 ? launch<true, true, 0, EPI_NONE, true>(g, splits, st)
+                             : launch<true, true, 1, EPI_NONE, true>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

@@ -83,10 +83,10 @@ struct RecArgs {
     const u32x4* vpack; const float* rec0;
     const float* u0; const float* w0; const float* s0;
     float theta, p_drop, inv_keep; uint64_t seed;
-    float* s_out; float* u_save; float* w_save; uint32_t* spike_count;
+    float* s_out; uint16_t* s16_out; float* u_save; float* w_save; uint32_t* spike_count;
     // backward
     const float* g_out; const float* g_rate; float g_rate_scale;
-    float* dWx; float* s_prev; float* dparam_ws;
+    float* dWx; uint16_t* s_prev16; float* dparam_ws;
     // hand-off
     u64* chan; unsigned* flags; char* ring; unsigned* status;
 };
@@ -238,7 +238,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     auto flush_pending = [&]() {
         if (pend_t >= 0 && valid) {
             const int ptt = d ? (T - 1 - pend_t) : pend_t;
-            st4(a.s_out + ((size_t)b * T + ptt) * HO + (size_t)d * H + colc, pend_s);
+            const size_t o_s = ((size_t)b * T + ptt) * HO + (size_t)d * H + colc;
+            st4(a.s_out + o_s, pend_s);
+            if (a.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
+                u32x2 h;
+                h.x = (pend_s[0] != 0.f ? 0x3F80u : 0u) | (pend_s[1] != 0.f ? 0x3F800000u : 0u);
+                h.y = (pend_s[2] != 0.f ? 0x3F80u : 0u) | (pend_s[3] != 0.f ? 0x3F800000u : 0u);
+                *reinterpret_cast<u32x2*>(a.s16_out + o_s) = h;
+            }
             st4(a.u_save + ((size_t)bp * T + pend_t) * H + col, pend_u);
             if (ADAPT) st4(a.w_save + ((size_t)bp * T + pend_t) * H + col, pend_w);
         }
@@ -666,7 +673,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
         if (valid) {
             st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
-            st4(a.s_prev + ((size_t)bp * T + tt) * H + col, spv);
+            u32x2 h;  // s_{t-1} (binary for t >= 1, zero row at t = 0) as a bf16 plane for the dV product
+            h.x = (spv[0] != 0.f ? 0x3F80u : 0u) | (spv[1] != 0.f ? 0x3F800000u : 0u);
+            h.y = (spv[2] != 0.f ? 0x3F80u : 0u) | (spv[3] != 0.f ? 0x3F800000u : 0u);
+            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt) * H + col) = h;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -879,7 +889,7 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
                                    const float* beta, const float* a, const float* b,
                                    const float* vpack, const float* rec0, const float* u0,
                                    const float* w0, const float* s0, float theta, float p_drop,
-                                   uint64_t seed, float* s_out, float* u_save, float* w_save,
+                                   uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
                                    uint32_t* spike_count, void* chan, size_t chan_bytes,
                                    uint32_t* status, int steps_per_launch, void* stream) {
     SPARCH_ENTER();
@@ -890,14 +900,14 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
-    if (!al16({Wx, vpack, rec0, u0, w0, s0, s_out, u_save, w_save, chan})) return SPARCH_EALIGN;
+    if (!al16({Wx, vpack, rec0, u0, w0, s0, s_out, s16_out, u_save, w_save, chan})) return SPARCH_EALIGN;
     RecArgs r{};
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
     r.Wx = Wx; r.scale = scale; r.shift = shift;
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
     r.vpack = reinterpret_cast<const u32x4*>(vpack); r.rec0 = rec0; r.u0 = u0; r.w0 = w0; r.s0 = s0;
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
-    r.s_out = s_out; r.u_save = u_save; r.w_save = w_save; r.spike_count = spike_count;
+    r.s_out = s_out; r.s16_out = s16_out; r.u_save = u_save; r.w_save = w_save; r.spike_count = spike_count;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<false>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }
@@ -907,18 +917,18 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
                                    const float* alpha, const float* beta, const float* a,
                                    const float* b, const float* vpack_t, const float* u0,
                                    const float* w0, const float* s0, float theta, float p_drop,
-                                   uint64_t seed, float* dWx, float* s_prev, float* dparam_ws,
+                                   uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
                                    void* chan, size_t chan_bytes, uint32_t* status,
                                    int steps_per_launch, void* stream) {
     SPARCH_ENTER();
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
-    if (!g_out || !u_save || !alpha || !vpack_t || !u0 || !s0 || !dWx || !s_prev || !dparam_ws || !status)
+    if (!g_out || !u_save || !alpha || !vpack_t || !u0 || !s0 || !dWx || !s_prev16 || !dparam_ws || !status)
         return SPARCH_EINVAL;
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
-    if (!al16({g_out, u_save, w_save, vpack_t, u0, w0, s0, dWx, s_prev, dparam_ws, chan})) return SPARCH_EALIGN;
+    if (!al16({g_out, u_save, w_save, vpack_t, u0, w0, s0, dWx, s_prev16, dparam_ws, chan})) return SPARCH_EALIGN;
     if (bwd_ring_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
     RecArgs r{};
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
@@ -927,7 +937,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
     r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
-    r.dWx = dWx; r.s_prev = s_prev; r.dparam_ws = dparam_ws;
+    r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<true>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }

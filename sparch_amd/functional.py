@@ -18,6 +18,8 @@ from ._capi import KIND, check, lib, ptr
 
 # Exact bf16-split MFMA GEMMs for spike operands (SPARCH_SPIKE_GEMM=0 forces the fp32 MFMA everywhere).
 USE_SPIKE_GEMM = os.environ.get("SPARCH_SPIKE_GEMM", "1") != "0"
+# spike operands travel between layers as bf16 0/1 planes next to the fp32 tensors (half the GEMM operand bytes)
+USE_SPIKE16 = os.environ.get("SPARCH_SPIKE16", "1") != "0"
 
 # Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
@@ -117,16 +119,21 @@ def flag_bf16_exact(x):
     return flag
 
 
-def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None):
+def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None, a16=None):
     """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials.
-    spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path."""
+    spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path;
+    a16: the same spikes as a (M,K) bf16 0/1 plane (read instead of A)."""
     M, K = A.shape
     N = B.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
     ws = None
     if colstat:
         ws = torch.empty(2 * ((M + 127) // 128) * N, dtype=torch.float32, device=A.device)
-    if spike_scale is not None and USE_SPIKE_GEMM:
+    if spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16:
+        tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_spike16_nt(M, N, K, ptr(a16), a16.stride(0), float(spike_scale), ptr(B), B.stride(0),
+                                         ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike16_nt")
+    elif spike_scale is not None and USE_SPIKE_GEMM:
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
                                        ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
@@ -155,15 +162,25 @@ def gemm_nn(A, B):
     return C
 
 
-def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b_exact_flag=None):
+def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b_exact_flag=None, spike16=False):
     """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis.
-    spike_side 0/1: A / B is a spike tensor (entries 0 or spike_scale) -> exact bf16-split MFMA path.
+    spike_side 0/1: A / B is a spike tensor (entries 0 or spike_scale) -> exact bf16-split MFMA path;
+    spike16: that operand is given as a bf16 0/1 plane (torch.bfloat16).
     out: accumulate into this (M,N) tensor instead of allocating."""
     K, M = A.shape
     N = B.shape[1]
     accumulate = out is not None
     C = out if accumulate else torch.empty(M, N, dtype=torch.float32, device=A.device)
-    if spike_side is not None and USE_SPIKE_GEMM:
+    if spike16 and not (spike_side is not None and USE_SPIKE_GEMM):
+        raise RuntimeError("internal: a bf16 spike plane needs the spike GEMM path")
+    if spike_side is not None and USE_SPIKE_GEMM and spike16:
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        tok = timer.start(f"gemm_spike_tn[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_spike16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
+                                         float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
+                                         ptr(ws), nbytes, _stream()), "sparch_gemm_spike16_tn")
+    elif spike_side is not None and USE_SPIKE_GEMM:
         nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_spike_tn[{M}x{N}x{K}]")
@@ -281,13 +298,16 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
     """Run one spiking cell over the whole sequence on the device.
 
     Wx (B,T,H) raw projection (+ optional per-column scale/shift); u0/w0/s0 (B*dirs,H).
-    Returns (s_out (B,T,H*dirs), count (H*dirs) int32, saved) where saved feeds cell_backward."""
+    Returns (s_out (B,T,H*dirs), count (H*dirs) int32, saved, s16) where saved feeds cell_backward and s16 is
+    s_out != 0 as a bf16 plane (or None)."""
     _, T, H = Wx.shape
     Bp = B * dirs
     dev = Wx.device
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
     s_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
+    # the same spikes as a bf16 0/1 plane for the GEMMs of the next layer (rows must stay 16-byte aligned)
+    s16 = torch.empty(B, T, H * dirs, dtype=torch.bfloat16, device=dev) if (USE_SPIKE_GEMM and USE_SPIKE16) else None
     u_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
     w_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev) if adaptive else None
     count = torch.zeros(H * dirs, dtype=torch.int32, device=dev)
@@ -295,7 +315,7 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         tok = timer.start(f"cell_fwd[{kind}]")
         check(lib.sparch_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                   ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0), ptr(w0),
-                                  ptr(s0), theta, p_drop, seed, ptr(s_out), ptr(u_save), ptr(w_save),
+                                  ptr(s0), theta, p_drop, seed, ptr(s_out), ptr(s16), ptr(u_save), ptr(w_save),
                                   ptr(count), _stream()), "sparch_cell_fwd")
         timer.stop(tok)
     else:
@@ -313,10 +333,10 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                       ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
                                       ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
-                                      ptr(u_save), ptr(w_save), ptr(count), ptr(chan), nbytes,
+                                      ptr(s16), ptr(u_save), ptr(w_save), ptr(count), ptr(chan), nbytes,
                                       ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
         timer.stop(tok)
-    return s_out, count, (u_save, w_save)
+    return s_out, count, (u_save, w_save), s16
 
 
 def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, theta, p_drop, seed,
@@ -343,7 +363,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
         V = p["V"]
         vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
         check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
-        s_prev = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+        s_prev = torch.empty(Bp, T, H, dtype=torch.bfloat16, device=dev)  # bf16 0/1 plane
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
@@ -357,8 +377,10 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
         # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
         # (cell step 0 sits at original time 0 for the forward direction, T-1 for the flipped one)
-        dV = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True,
-                     spike_side=0 if USE_SPIKE_GEMM else None)
+        if USE_SPIKE_GEMM:
+            dV = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True, spike_side=0, spike16=True)
+        else:  # fp32-MFMA comparison path (tests)
+            dV = gemm_tn(s_prev.view(Bp * T, H).float(), dWx.view(Bp * T, H), zero_diag=True)
         if True:  # s_prev rows of cell step 0 are zero on both paths
             for dd in range(dirs):
                 rows = slice(dd * B, (dd + 1) * B)
@@ -391,14 +413,16 @@ class SpikingLayerFn(torch.autograd.Function):
         # otherwise (network input): let the device decide whether x is bf16-exact (binned spike counts are)
         xflag = flag_bf16_exact(x2) if (in_scale is None and USE_SPIKE_GEMM) else None
         ctx.xflag = xflag
+        x16 = cfg.get("in_spike16") if in_scale is not None else None
+        x16 = x16.view(M, K) if x16 is not None else None
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale,
-                                  a_exact_flag=xflag)  # snns.py:261
+                                  a_exact_flag=xflag, a16=x16)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
         p = {k_: v for k_, v in p.items() if v is not None}
-        s_out, count, saved = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B, dirs=dirs,
-                                           theta=theta, p_drop=p_drop, seed=seed)
+        s_out, count, saved, s16 = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B,
+                                                dirs=dirs, theta=theta, p_drop=p_drop, seed=seed)
         inv_keep = 1.0 / (1.0 - p_drop)
         rate = count.to(torch.float32) * (inv_keep / float(B * T))  # snns.py:174 on post-dropout spikes
         ctx.cfg = cfg
@@ -407,10 +431,13 @@ class SpikingLayerFn(torch.autograd.Function):
         ctx.cell_saved = saved
         ctx.save_for_backward(x2, W, nw, alpha, beta, a, b, V, u0, w0, s0,
                               Wx_raw if norm in ("batchnorm", "layernorm") else None)
-        return s_out, rate
+        if s16 is None:  # keep the output arity fixed
+            s16 = torch.empty(0, dtype=torch.bfloat16, device=x.device)
+        ctx.mark_non_differentiable(s16)
+        return s_out, rate, s16
 
     @staticmethod
-    def backward(ctx, g_s, g_rate):
+    def backward(ctx, g_s, g_rate, _g_s16=None):
         cfg = ctx.cfg
         kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
         B, T, K, H = ctx.shape
@@ -435,7 +462,10 @@ class SpikingLayerFn(torch.autograd.Function):
         dy = dy.view(M, H)
         dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
         in_scale = cfg.get("in_spike_scale")
-        if in_scale is not None and USE_SPIKE_GEMM:
+        x16 = cfg.get("in_spike16") if (in_scale is not None and USE_SPIKE16) else None
+        if x16 is not None and USE_SPIKE_GEMM:
+            dW = gemm_tn(dx_raw, x16.view(M, K), spike_side=1, spike_scale=in_scale, spike16=True)
+        elif in_scale is not None and USE_SPIKE_GEMM:
             dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
         else:
             dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag)
@@ -460,8 +490,10 @@ class ReadoutLayerFn(torch.autograd.Function):
             raise ValueError("sparch_amd: readout layer supports at most 64 classes")
         M = B * T
         x2 = x.view(M, K)
+        x16 = cfg.get("in_spike16") if cfg.get("in_spike_scale") is not None else None
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training),
-                                  spike_scale=cfg.get("in_spike_scale"))  # snns.py:796
+                                  spike_scale=cfg.get("in_spike_scale"),
+                                  a16=x16.view(M, K) if x16 is not None else None)  # snns.py:796
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, 1)  # 799-801
         out = torch.empty(B, C, dtype=torch.float32, device=x.device)
@@ -492,7 +524,10 @@ class ReadoutLayerFn(torch.autograd.Function):
         dy = dWx.view(M, C)
         dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
         in_scale = cfg.get("in_spike_scale")
-        if in_scale is not None and USE_SPIKE_GEMM:
+        x16 = cfg.get("in_spike16") if (in_scale is not None and USE_SPIKE16) else None
+        if x16 is not None and USE_SPIKE_GEMM:
+            dW = gemm_tn(dx_raw, x16.view(M, K), spike_side=1, spike_scale=in_scale, spike16=True)
+        elif in_scale is not None and USE_SPIKE_GEMM:
             dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)
         else:
             dW = gemm_tn(dx_raw, x2)
@@ -511,8 +546,8 @@ class SpikingCellFn(torch.autograd.Function):
         Wx = _f32c(Wx)
         Bp, T, H = Wx.shape
         p = {k_: v for k_, v in dict(alpha=alpha, beta=beta, a=a, b=b, V=V).items() if v is not None}
-        s, _, saved = cell_forward(kind, Wx, None, None, p, u0, w0, s0, B=Bp, dirs=1, theta=theta, p_drop=0.0,
-                                   seed=0, steps_per_launch=steps_per_launch)
+        s, _, saved, _ = cell_forward(kind, Wx, None, None, p, u0, w0, s0, B=Bp, dirs=1, theta=theta, p_drop=0.0,
+                                      seed=0, steps_per_launch=steps_per_launch)
         ctx.kind, ctx.theta, ctx.dims, ctx.cell_saved, ctx.spl = kind, theta, (Bp, T, H), saved, steps_per_launch
         ctx.save_for_backward(alpha, beta, a, b, V, u0, w0, s0)
         return s

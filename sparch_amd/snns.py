@@ -162,16 +162,18 @@ class _SpikingLayer(nn.Module):
             "running_var": self.norm.running_var if is_bn else None,
             # set when x came straight out of one of our spiking layers: entries are 0 or this constant
             "in_spike_scale": getattr(x, "_sparch_spike_scale", None),
+            "in_spike16": getattr(x, "_sparch_spike16", None),  # the same spikes as a bf16 plane
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1
         nw = self.norm.weight if self.normalize else None
         nb = self.norm.bias if self.normalize else None
-        s, rate = Fn.SpikingLayerFn.apply(
+        s, rate, s16 = Fn.SpikingLayerFn.apply(
             cfg, x, self.W.weight, self.W.bias, nw, nb, self.alpha,
             getattr(self, "beta", None), getattr(self, "a", None), getattr(self, "b", None),
             self.V.weight if hasattr(self, "V") else None, u0, w0, s0)
         s._sparch_spike_scale = 1.0 / (1.0 - p_drop)  # lets the next layer take the exact bf16-split GEMMs
+        s._sparch_spike16 = s16                       # ... and read the spikes as a bf16 plane (half the bytes)
         return s, rate
 
     def forward(self, x):
@@ -253,6 +255,7 @@ class ReadoutLayer(nn.Module):
             "running_mean": self.norm.running_mean if is_bn else None,
             "running_var": self.norm.running_var if is_bn else None,
             "in_spike_scale": getattr(x, "_sparch_spike_scale", None),
+            "in_spike16": getattr(x, "_sparch_spike16", None),  # the same spikes as a bf16 plane
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1

@@ -36,7 +36,7 @@ def test_prototype_arity_matches_header():
 
 def test_host_only_entry_points():
     lib = _capi.lib
-    assert lib.sparch_abi_version() == 1
+    assert lib.sparch_abi_version() == 2
     assert _capi.strerror(0) == "ok" and "workspace" in _capi.strerror(-3)
     assert lib.sparch_fbank_frames(16000) == 98 and lib.sparch_fbank_frames(399) == 0
     assert lib.sparch_vpack_bytes(1024) == 1024 * 1024 * 6   # three bf16 planes per fp32 element
@@ -52,4 +52,4 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.sparch_gemm_nt(0, 4, 4, None, 4, None, 4, None, 4, None, None, None) == -1
     assert lib.sparch_readout_fwd(2, 3, 65, 1, None, None, 1, 1, 1, None, None) == -1  # C > 64
     assert lib.sparch_cell_fwd(2, 1, 1, 1, 4, 16, None, None, 16, None, None, None, 16, None, 16,
-                               1.0, 0.0, 0, 16, None, None, None, None) == -1  # kind RLIF on non-recurrent entry
+                               1.0, 0.0, 0, 16, None, None, None, None, None) == -1  # kind RLIF on non-recurrent entry

@@ -103,7 +103,8 @@ def test_gemm_tn_splitk_deterministic(M, N, K, zd, dense_impl):
     assert torch.equal(C, C2), "split-K reduction must be bitwise reproducible"
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 70, 700), (257, 35, 1024), (1000, 1024, 96), (64, 129, 44)])
+@pytest.mark.parametrize("M,N,K", [(300, 70, 700), (257, 35, 1024), (1000, 1024, 96), (64, 129, 44),
+                                   (1536, 256, 512), (520, 384, 1000)])
 def test_gemm_spike_nt_exact_split(M, N, K):
     """A in {0, c}: C = c * (A != 0) @ B^T with B split exactly into three bf16 planes."""
     Fn = _Fn()
@@ -124,11 +125,17 @@ def test_gemm_spike_nt_exact_split(M, N, K):
     A1 = (A != 0).float()
     C1, _ = Fn.gemm_nt(A1.to(DEV), Bd.to(DEV), spike_scale=1.0)
     assert torch.equal(C1.cpu().double(), A1.double() @ Bd.double().T)
+    # the same spikes given as a bf16 0/1 plane: identical products, so identical results bit for bit
+    # (a plane with rows of K elements: 16-byte loadable only when K % 8 == 0, element-wise otherwise)
+    a16 = (A != 0).to(torch.bfloat16).to(DEV)
+    C16, ws16 = Fn.gemm_nt(A.to(DEV), B.to(DEV), bias.to(DEV), colstat=True, spike_scale=c, a16=a16)
+    assert torch.equal(C16, C) and torch.equal(ws16, ws)
 
 
 @pytest.mark.parametrize("M,N,K,side,zd", [(128, 700, 3000, 0, False), (96, 96, 5000, 0, True),
                                            (1024, 260, 2048, 1, False), (35, 1024, 4096, 1, False),
-                                           (700, 35, 1111, 0, False)])
+                                           (700, 35, 1111, 0, False), (512, 520, 8192, 0, True),
+                                           (264, 512, 9000, 1, False)])
 def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
     Fn = _Fn()
     g = torch.Generator().manual_seed(K + side)
@@ -148,6 +155,11 @@ def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
     assert bool((err <= bound).all()), float((err / bound).max())
     C2 = Fn.gemm_tn(A.to(DEV), B.to(DEV), zero_diag=zd, spike_side=side, spike_scale=c)
     assert torch.equal(C, C2)
+    # the spike operand as a bf16 0/1 plane: bit-identical result
+    A16 = (A != 0).to(torch.bfloat16).to(DEV) if side == 0 else A.to(DEV)
+    B16 = (B != 0).to(torch.bfloat16).to(DEV) if side == 1 else B.to(DEV)
+    C3 = Fn.gemm_tn(A16, B16, zero_diag=zd, spike_side=side, spike_scale=c, spike16=True)
+    assert torch.equal(C, C3)
     # accumulate mode of the fp32 TN GEMM (used for the t = 0 term of dV)
     acc = C.clone()
     Fn.gemm_tn(A[:64].to(DEV), B[:64].to(DEV), zero_diag=zd, out=acc)
@@ -279,10 +291,11 @@ def test_bidirectional_cell_addressing_bit_exact(kind, B, T, H, p_drop):
     pd = {k: v.detach().to(DEV) for k, v in p.items()}
     Wxd = Wx.detach().to(DEV)
     seed = 1234567
-    s_out, count, saved = Fn.cell_forward(kind, Wxd, None, None, pd, u0.to(DEV), None if w0 is None else w0.to(DEV),
+    s_out, count, saved, s16 = Fn.cell_forward(kind, Wxd, None, None, pd, u0.to(DEV), None if w0 is None else w0.to(DEV),
                                           s0.to(DEV), B=B, dirs=2, theta=1.0, p_drop=p_drop, seed=seed)
     Fn.check_status()
     out = s_out.cpu()
+    assert torch.equal(s16.float().cpu(), (out != 0).float())  # the bf16 plane is exactly (s_out != 0)
     if p_drop == 0.0:
         assert torch.equal(out, ref.detach())
         dWx, pg = Fn.cell_backward(kind, gs.to(DEV), None, pd, u0.to(DEV), None if w0 is None else w0.to(DEV),
