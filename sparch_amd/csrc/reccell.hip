@@ -357,10 +357,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         }
         // ---- publish this tile's spikes first (it is on every consumer's critical path): one
         //      tagged granule per row; dropout and the bulk stores then overlap the peers' step
+        // OR over the 8 lanes of a row with DPP moves (quad xor 1, quad xor 2, then the mirrored half row
+        // brings in the other quad) — __shfl_xor would go through the LDS crossbar three times in a row
         unsigned word = nib << (cq * 4);
-        word |= __shfl_xor(word, 1);
-        word |= __shfl_xor(word, 2);
-        word |= __shfl_xor(word, 4);
+        word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x141, 0xF, 0xF, true);  // row_half_mirror
         if (pw && cq == 0 && t + 1 < T) {
             gu64* slot = (gu64*)a.chan + (((size_t)t * a.n_rt_total + rt) * a.n_ct + ct) * 32 + r;
             __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED, REC_ST_SCOPE);
