@@ -338,8 +338,10 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Renumber so
     // that an XCD owns a CONTIGUOUS range of (split, tile_m, tile_n): tiles that share an operand panel
     // then share one L2 instead of pulling the panel through all eight.
-    int lin = blockIdx.x;
-    if ((gridDim.x & 7) == 0) lin = (lin & 7) * (gridDim.x >> 3) + (lin >> 3);
+    // (any grid size: XCD x receives ceil or floor of grid/8 workgroups, the first grid%8 XCDs one more)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per = gridDim.x >> 3, extra = gridDim.x & 7;
+    const int lin = xcd * per + min(xcd, extra) + idx;
     const int tiles_all = tiles_n * ((g.M + BM - 1) / BM);
     const int split = lin / tiles_all, tile = lin - split * tiles_all;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
