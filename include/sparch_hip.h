@@ -284,6 +284,24 @@ int sparch_bin_events(long long n_events, const float* times, const int* units,
                       const long long* sample_offsets, int n_samples, int nb_steps, int nb_units,
                       double max_time, float* out, uint32_t* n_dropped, void* stream);
 
+/* ---- f-4: non-spiking baselines (anns.py) --------------------------------------------------
+ * Element-wise tail of MLPLayer.forward (anns.py:218-227): y = dropout(act(z * scale + shift)) over n
+ * elements of an (n/H, H) tensor; scale/shift (H) = the folded BatchNorm affine, NULL for none.
+ * Backward: dz = dy * keep * act'(z * scale + shift) — the gradient w.r.t. the NORMALISED
+ * pre-activation (feed it to the norm's backward).  H % 4 == 0.                                   */
+#define SPARCH_ACT_SIGMOID 0
+#define SPARCH_ACT_RELU 1
+#define SPARCH_ACT_TANH 2
+int sparch_act_fwd(int kind, size_t n, int H, const float* z, const float* scale, const float* shift,
+                   float p_drop, uint64_t seed, float* y, void* stream);
+int sparch_act_bwd(int kind, size_t n, int H, const float* z, const float* scale, const float* shift,
+                   const float* dy, float p_drop, uint64_t seed, float* dz, void* stream);
+/* ReadoutLayerANN._readout_cell (anns.py:658-665): out[b,:] = sum_t softmax(x[b,t,:]) (softmax over the
+ * K features, accumulated in time order); backward dx[b,t,:] = p_t * (g[b,:] - <p_t, g[b,:]>).
+ * K % 4 == 0, K <= 4096.                                                                          */
+int sparch_softmax_sum_fwd(int B, int T, int K, const float* x, float* out, void* stream);
+int sparch_softmax_sum_bwd(int B, int T, int K, const float* x, const float* g, float* dx, void* stream);
+
 /* ---- f-2: optimizer step on the device (replaces torch.optim.Adam.step, exp.py:89, 377) ----------
  * One launch for the whole parameter list; arithmetic identical, operation by operation, to
  * torch.optim.Adam's default path (see optim.hip).  `params`, `grads`, `exp_avg`, `exp_avg_sq` are HOST

@@ -75,6 +75,10 @@ PROTOTYPES = {
     "sparch_fbank_frames": (c_int, [c_int]),
     "sparch_fbank_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
     "sparch_bin_events": (c_int, [c_longlong, P, P, P, c_int, c_int, c_int, c_double, P, P, P]),
+    "sparch_act_fwd": (c_int, [c_int, c_size_t, c_int, P, P, P, c_float, c_uint64, P, P]),
+    "sparch_act_bwd": (c_int, [c_int, c_size_t, c_int, P, P, P, P, c_float, c_uint64, P, P]),
+    "sparch_softmax_sum_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
+    "sparch_softmax_sum_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P]),
     "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

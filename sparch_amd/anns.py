@@ -1,0 +1,231 @@
+"""
+Non-spiking baselines with the reference's module API (sparch/models/anns.py).
+
+`ANN`, `MLPLayer`, `RNNLayer`, `LiGRULayer`, `GRULayer`, `ReadoutLayerANN` keep the reference's names,
+constructor signatures, parameter names / shapes (state_dict keys) and the order of RNG draws at
+construction (anns.py:57-131, 173-208, 255-293, 367-410, 490-538, 617-642).  The arithmetic of MLP layers
+and of the readout runs in libsparch_hip.so (projection GEMMs on the exact bf16 split, BatchNorm folded
+into the activation kernel, softmax-sum readout); the recurrent baselines (RNN, LiGRU, GRU) are constructed
+and check-pointable but their forward is not implemented in this round and raises — there is no CPU
+fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .snns import _SpikingLayer  # dropout seed helper
+
+
+def _make_norm(layer, name, normalization, size):
+    if normalization == "batchnorm":
+        setattr(layer, name, nn.BatchNorm1d(size, momentum=0.05))
+        return True
+    if normalization == "layernorm":
+        setattr(layer, name, nn.LayerNorm(size))
+        return True
+    return False
+
+
+class ANN(nn.Module):
+    """anns.py:19-146.  forward(x (B,T,C)) -> (out, None): (B,classes) with the readout layer, else (B,T,H)."""
+
+    def __init__(self, input_shape, layer_sizes, ann_type="MLP", dropout=0.0, normalization="batchnorm",
+                 use_bias=False, bidirectional=False, use_readout_layer=True):
+        super().__init__()
+        self.reshape = True if len(input_shape) > 3 else False
+        self.input_size = float(torch.prod(torch.tensor(input_shape[2:])))
+        self.batch_size = input_shape[0]
+        self.layer_sizes = layer_sizes
+        self.num_layers = len(layer_sizes)
+        self.num_outputs = layer_sizes[-1]
+        self.ann_type = ann_type
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.use_readout_layer = use_readout_layer
+        self.is_snn = False
+        if ann_type not in ["MLP", "RNN", "LiGRU", "GRU"]:
+            raise ValueError(f"Invalid ann type {ann_type}")
+        if bidirectional and ann_type == "MLP":
+            raise ValueError("MLP cannot be bidirectional.")
+        self.ann = self._init_layers()
+
+    def _init_layers(self):
+        ann = nn.ModuleList([])
+        input_size = self.input_size
+        ann_class = self.ann_type + "Layer"
+        num_hidden_layers = self.num_layers - 1 if self.use_readout_layer else self.num_layers
+        for i in range(num_hidden_layers):
+            layer = globals()[ann_class](input_size=input_size, hidden_size=self.layer_sizes[i],
+                                         batch_size=self.batch_size, dropout=self.dropout,
+                                         normalization=self.normalization, use_bias=self.use_bias,
+                                         bidirectional=self.bidirectional)
+            layer._layer_index = i
+            ann.append(layer)
+            input_size = self.layer_sizes[i] * (1 + self.bidirectional)
+        if self.use_readout_layer:
+            ann.append(ReadoutLayerANN(input_size=input_size, output_size=self.layer_sizes[-1],
+                                       normalization=self.normalization, use_bias=self.use_bias))
+        return ann
+
+    def forward(self, x):
+        if self.reshape:
+            if x.ndim == 4:
+                x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+            else:
+                raise (NotImplementedError)
+        for ann_lay in self.ann:
+            x = ann_lay(x)
+        return x, None  # so that same as SNN (anns.py:146)
+
+
+class _ANNLayer(nn.Module):
+    _dropout_seed = _SpikingLayer._dropout_seed
+
+    def _norm_args(self, norm_name="norm"):
+        is_bn = self.normalization == "batchnorm"
+        norm = getattr(self, norm_name) if self.normalize else None
+        if is_bn and self.training:
+            norm.num_batches_tracked += 1
+        return (norm.weight if norm is not None else None, norm.bias if norm is not None else None,
+                norm.running_mean if is_bn else None, norm.running_var if is_bn else None)
+
+
+class MLPLayer(_ANNLayer):
+    """anns.py:149-227: y = dropout(sigmoid(norm(W x)))."""
+
+    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
+                 use_bias=False, bidirectional=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.act_fct = nn.Sigmoid()
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
+        self.drop = nn.Dropout(p=dropout)
+
+    def forward(self, x):
+        Fn._require_device(x, "input")
+        if self.batch_size != x.shape[0]:
+            self.batch_size = x.shape[0]
+        p_drop = float(self.dropout) if self.training else 0.0
+        nw, nb, rm, rv = self._norm_args()
+        cfg = {"act": "sigmoid", "normalization": self.normalization, "training": self.training, "p_drop": p_drop,
+               "seed": self._dropout_seed(x.device) if p_drop > 0 else 0, "running_mean": rm, "running_var": rv}
+        return Fn.MLPLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)
+
+
+class _RecurrentANNLayer(_ANNLayer):
+    KIND = None
+
+    def forward(self, x):
+        raise NotImplementedError(
+            f"sparch_amd: the {self.KIND} baseline's recurrent cell has no HIP kernel in this round "
+            "(SURVEY.md §8 f-4); MLP and the ANN readout do")
+
+
+class RNNLayer(_RecurrentANNLayer):
+    """anns.py:230-339 (constructor parity; forward pending)."""
+    KIND = "RNN"
+
+    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
+                 use_bias=False, bidirectional=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.batch_size = self.batch_size * (1 + bidirectional)
+        self.act_fct = nn.Sigmoid()
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        nn.init.orthogonal_(self.V.weight)
+        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
+        self.drop = nn.Dropout(p=dropout)
+
+
+class LiGRULayer(_RecurrentANNLayer):
+    """anns.py:342-462 (constructor parity; forward pending)."""
+    KIND = "LiGRU"
+
+    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
+                 use_bias=False, bidirectional=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.batch_size = self.batch_size * (1 + bidirectional)
+        self.act_fct = nn.ReLU()
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        self.Wz = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.Vz = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        nn.init.orthogonal_(self.V.weight)
+        nn.init.orthogonal_(self.Vz.weight)
+        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
+        if self.normalize:
+            _make_norm(self, "normz", normalization, self.hidden_size)
+        self.drop = nn.Dropout(p=dropout)
+
+
+class GRULayer(_RecurrentANNLayer):
+    """anns.py:465-595 (constructor parity; forward pending)."""
+    KIND = "GRU"
+
+    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
+                 use_bias=False, bidirectional=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.bidirectional = bidirectional
+        self.batch_size = self.batch_size * (1 + bidirectional)
+        self.act_fct = nn.Tanh()
+        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        self.Wz = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.Vz = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        self.Wr = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
+        self.Vr = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
+        nn.init.orthogonal_(self.V.weight)
+        nn.init.orthogonal_(self.Vz.weight)
+        nn.init.orthogonal_(self.Vr.weight)
+        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
+        if self.normalize:
+            _make_norm(self, "normz", normalization, self.hidden_size)
+            _make_norm(self, "normr", normalization, self.hidden_size)
+        self.drop = nn.Dropout(p=dropout)
+
+
+class ReadoutLayerANN(_ANNLayer):
+    """anns.py:598-665: norm(W sum_t softmax(x_t)) -> (B, classes)."""
+
+    def __init__(self, input_size, output_size, normalization="batchnorm", use_bias=False):
+        super().__init__()
+        self.input_size = int(input_size)
+        self.output_size = int(output_size)
+        self.normalization = normalization
+        self.use_bias = use_bias
+        self.W = nn.Linear(self.input_size, self.output_size, bias=use_bias)
+        self.normalize = _make_norm(self, "norm", normalization, self.output_size)
+
+    def forward(self, x):
+        Fn._require_device(x, "input")
+        nw, nb, rm, rv = self._norm_args()
+        cfg = {"normalization": self.normalization, "training": self.training, "running_mean": rm, "running_var": rv}
+        return Fn.ReadoutANNFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)

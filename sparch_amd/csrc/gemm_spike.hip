@@ -324,7 +324,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
     constexpr int WI = S::WI, WJ = S::WJ, WN = S::WN, BM = S::BM, BN = S::BN, NT = S::NT;
-    constexpr int A_PLANES = SPIKE_A ? 1 : 3, B_PLANES = SPIKE_B ? 1 : 3;
+    constexpr int A_PLANES = SPIKE_A ? 1 : 3;
+    [[maybe_unused]] constexpr int B_PLANES = SPIKE_B ? 1 : 3;
     constexpr int PLANE_A = plane_elems<A_KM, BM>(), PLANE_B = plane_elems<B_KM, BN>();
     constexpr int STAGE = stage_elems<A_KM, B_KM, MODE, FAST>();
     unsigned short* const lds = dyn_lds;  // [FAST ? 2 : 1][A planes | B planes]

@@ -30,6 +30,7 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau
 from . import dp, optim
 from .functional import check_status, fbank
 from .parsers import print_model_options, print_training_options
+from .anns import ANN
 from .snns import SNN
 
 logger = logging.getLogger(__name__)
@@ -202,9 +203,12 @@ class Experiment:
                            bidirectional=self.bidirectional, use_readout_layer=True).to(self.device)
             logging.info(f"\nCreated new spiking model:\n {self.net}\n")
         elif self.model_type in ["MLP", "RNN", "LiGRU", "GRU"]:
-            raise NotImplementedError(
-                f"sparch_amd: the non-spiking baselines ({self.model_type}) are outside this build's hot path "
-                "(SURVEY.md §8 f-4)")
+            # exp.py:311-322.  MLP runs on the HIP path; the recurrent baselines construct (checkpoints,
+            # parameter counts) but their forward raises (pending).
+            self.net = ANN(input_shape=input_shape, layer_sizes=layer_sizes, ann_type=self.model_type,
+                           dropout=self.pdrop, normalization=self.normalization, use_bias=self.use_bias,
+                           bidirectional=self.bidirectional, use_readout_layer=True).to(self.device)
+            logging.info(f"\nCreated new non-spiking model:\n {self.net}\n")
         else:
             raise ValueError(f"Invalid model type {self.model_type}")
         if self.world > 1:  # identical initial replicas

@@ -632,3 +632,92 @@ def bin_events(times, units, nb_steps=100, nb_units=700, max_time=1.4, device="c
     check(lib.sparch_bin_events(n, ptr(t_d) if n else None, ptr(u_d) if n else None, ptr(o_d), len(lens), nb_steps,
                                 nb_units, float(max_time), ptr(out), ptr(dropped), _stream()), "sparch_bin_events")
     return out, dropped[:1]
+
+
+# ----------------------------------------------------------------------------- f-4: non-spiking baselines
+ACT_KIND = {"sigmoid": 0, "relu": 1, "tanh": 2}
+
+
+class MLPLayerFn(torch.autograd.Function):
+    """x (B,T,K) -> dropout(act(norm(W x))) (B,T,H): MLPLayer.forward, anns.py:210-227."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, W, Wb, nw, nb):
+        _require_device(x, "input")
+        _require_device(W, "layer parameters")
+        norm, training = cfg["normalization"], cfg["training"]
+        x = _f32c(x)
+        B, T, K = x.shape
+        H = W.shape[0]
+        if H % 4 != 0:
+            raise ValueError("sparch_amd: MLP layers need hidden_size % 4 == 0")
+        M = B * T
+        x2 = x.view(M, K)
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))          # anns.py:218
+        Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
+                                                    cfg.get("running_var"), training, 1)          # 221-223
+        y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
+        check(lib.sparch_act_fwd(ACT_KIND[cfg["act"]], M * H, H, ptr(Wx_in), ptr(scale), ptr(shift),
+                                 cfg["p_drop"], cfg["seed"], ptr(y), _stream()), "sparch_act_fwd")  # 226
+        ctx.cfg, ctx.shape, ctx.nsaved = cfg, (B, T, K, H), nsaved
+        ctx.save_for_backward(x2, W, nw, Wx_raw if norm in ("batchnorm", "layernorm") else None,
+                              Wx_in if norm != "batchnorm" else None, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        cfg = ctx.cfg
+        norm = cfg["normalization"]
+        B, T, K, H = ctx.shape
+        x2, W, nw, Wx_raw, Wx_in, scale, shift = ctx.saved_tensors
+        M = B * T
+        z = Wx_in if Wx_in is not None else Wx_raw
+        dz = torch.empty(M, H, dtype=torch.float32, device=x2.device)
+        check(lib.sparch_act_bwd(ACT_KIND[cfg["act"]], M * H, H, ptr(z), ptr(scale), ptr(shift), ptr(_f32c(g_y)),
+                                 cfg["p_drop"], cfg["seed"], ptr(dz), _stream()), "sparch_act_bwd")
+        dx_raw, dnw, dnb = _Norm.backward(norm, dz, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dW = gemm_tn(dx_raw, x2)
+        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
+        dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
+        return None, dx, dW, dWb, dnw, dnb
+
+
+class ReadoutANNFn(torch.autograd.Function):
+    """x (B,T,K) -> norm(W sum_t softmax(x_t)) (B,C): ReadoutLayerANN.forward, anns.py:644-665."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, W, Wb, nw, nb):
+        _require_device(x, "input")
+        _require_device(W, "layer parameters")
+        norm, training = cfg["normalization"], cfg["training"]
+        x = _f32c(x)
+        B, T, K = x.shape
+        C = W.shape[0]
+        if K % 4 != 0 or K > 4096:
+            raise ValueError("sparch_amd: ANN readout needs input features % 4 == 0 and <= 4096")
+        y = torch.empty(B, K, dtype=torch.float32, device=x.device)
+        check(lib.sparch_softmax_sum_fwd(B, T, K, ptr(x), ptr(y), _stream()), "sparch_softmax_sum_fwd")  # 658-663
+        Wy_raw, colstat = gemm_nt(y, W, Wb, colstat=(norm == "batchnorm" and training))                  # 650
+        Wy_in, scale, shift, nsaved = _Norm.forward(norm, Wy_raw, colstat, nw, nb, cfg.get("running_mean"),
+                                                    cfg.get("running_var"), training, 1)                 # 653-654
+        out = Wy_in if scale is None else Wy_in * scale + shift  # (B,C): tiny
+        ctx.cfg, ctx.shape, ctx.nsaved = cfg, (B, T, K, C), nsaved
+        ctx.save_for_backward(x, y, W, nw, Wy_raw if norm in ("batchnorm", "layernorm") else None, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        cfg = ctx.cfg
+        norm = cfg["normalization"]
+        B, T, K, C = ctx.shape
+        x, y, W, nw, Wy_raw, scale = ctx.saved_tensors
+        dz = _f32c(g_out).clone()
+        dx_raw, dnw, dnb = _Norm.backward(norm, dz, Wy_raw, nw, ctx.nsaved, cfg["training"])
+        dW = gemm_tn(dx_raw, y)
+        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            gy = gemm_nn(dx_raw, W)  # (B,K)
+            dx = torch.empty(B, T, K, dtype=torch.float32, device=x.device)
+            check(lib.sparch_softmax_sum_bwd(B, T, K, ptr(x), ptr(gy), ptr(dx), _stream()), "sparch_softmax_sum_bwd")
+        return None, dx, dW, dWb, dnw, dnb

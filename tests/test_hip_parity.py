@@ -766,3 +766,113 @@ def test_adam_step_matches_torch_adam():
     assert float(o_new.state_dict()["state"][0]["step"]) == 6.0
     with pytest.raises(NotImplementedError):
         Adam(p_gpu, amsgrad=True)
+
+
+# ------------------------------------------------------------------ f-4: non-spiking baselines (anns.py)
+def _ann_from_fixture(name):
+    import json
+
+    from sparch_amd.anns import ANN
+    from tests.golden_io import load
+
+    z = load(name)
+    cfg = json.loads(str(z["cfg"]))
+    net = ANN(input_shape=(cfg["B"], None, cfg["C"]), layer_sizes=cfg["layer_sizes"], ann_type=cfg["ann_type"],
+              dropout=0.0, normalization=cfg["normalization"], use_bias=cfg["use_bias"],
+              bidirectional=cfg["bidirectional"], use_readout_layer=cfg["use_readout_layer"])
+    net.load_state_dict({k[len("param."):]: torch.from_numpy(v) for k, v in z.items() if k.startswith("param.")})
+    return cfg, z, net.to(DEV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout"])
+def test_mlp_ann_matches_reference_fixture(name):
+    """The MLP baseline + ANN readout on the HIP path against the real reference's outputs, loss, gradients,
+    running statistics and eval-mode output (tests/golden/ann_MLP_*.npz).  fp32 tolerance, relative to each
+    tensor's largest entry: 2e-4 without the readout.  With it 1e-3 (outputs) / 3e-3 (gradients): the ANN
+    readout sums softmaxes of sigmoid outputs — nearly uniform, so W y varies little over the batch — and
+    its BatchNorm over the fixture's batch of 6 divides by that small deviation, which magnifies the
+    last-bit differences of expf and summation order about a thousandfold (re-ordering the time sum in
+    the CPU oracle alone moves the reference's own output by 2e-5)."""
+    cfg, z, net = _ann_from_fixture(name)
+    tol_out, tol_grad = (1e-3, 3e-3) if cfg["use_readout_layer"] else (2e-4, 5e-4)
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    net.train()
+    out, none = net(x)
+    assert none is None
+    assert relmax(out.detach().cpu().numpy(), z["out"]) <= tol_out
+    loss = torch.nn.functional.cross_entropy(out, y) if cfg["use_readout_layer"] else (out * out).mean()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= tol_out * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert relmax(p.grad.cpu().numpy(), z["grad." + k]) <= tol_grad, k
+    sd = net.state_dict()
+    for k in z:
+        if k.startswith("after."):
+            np.testing.assert_allclose(sd[k[len("after."):]].cpu().numpy(), z[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        out_e, _ = net(x)
+    assert relmax(out_e.cpu().numpy(), z["out_eval"]) <= tol_out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sigmoid", "relu", "tanh"])
+def test_act_kernels_vs_torch(kind):
+    """sparch_act_fwd/bwd (folded affine + activation + dropout) against torch fp32 on the CPU; the dropout
+    mask is the kernel's own (regenerated identically in the backward), checked through the outputs."""
+    from sparch_amd._capi import check, lib, ptr
+
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(3)
+    M, H = 37, 52
+    z = torch.randn(M, H, generator=g) * 2
+    sc, sh = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g) * 0.3
+    dy = torch.randn(M, H, generator=g)
+    f = {"sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[kind]
+    zz = (z * sc + sh).requires_grad_(True)
+    ref = f(zz)
+    ref.backward(dy)
+    # tanh: the device's tanhf and the host's differ by a few ulp, and 1 - a^2 cancels near saturation
+    ry, ay, rg, ag = (5e-6, 5e-7, 2e-4, 2e-6) if kind == "tanh" else (2e-6, 2e-7, 2e-5, 2e-7)
+    for p_drop in (0.0, 0.25):
+        y = torch.empty(M, H, device=DEV)
+        dz = torch.empty(M, H, device=DEV)
+        zd, scd, shd, dyd = z.to(DEV), sc.to(DEV), sh.to(DEV), dy.to(DEV)
+        k = Fn.ACT_KIND[kind]
+        check(lib.sparch_act_fwd(k, M * H, H, ptr(zd), ptr(scd), ptr(shd), p_drop, 99, ptr(y), Fn._stream()), "act_fwd")
+        check(lib.sparch_act_bwd(k, M * H, H, ptr(zd), ptr(scd), ptr(shd), ptr(dyd), p_drop, 99, ptr(dz), Fn._stream()), "act_bwd")
+        y, dz = y.cpu(), dz.cpu()
+        keep = 1.0 / (1.0 - p_drop)
+        if p_drop == 0.0:
+            torch.testing.assert_close(y, ref.detach(), rtol=ry, atol=ay)
+            torch.testing.assert_close(dz, zz.grad, rtol=rg, atol=ag)
+        else:
+            kept = (dz != 0) | (y != 0)
+            frac = float(kept.float().mean())
+            assert abs(frac - (1 - p_drop)) < 0.06 or kind == "relu"   # relu is zero on half its inputs anyway
+            torch.testing.assert_close(y[kept], (ref.detach() * keep)[kept], rtol=ry, atol=ay)
+            torch.testing.assert_close(dz[kept], (zz.grad * keep)[kept], rtol=rg, atol=ag)
+            assert bool((y[~kept] == 0).all()) and bool((dz[~kept] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,K", [(3, 17, 48), (5, 40, 1024), (2, 9, 2052)])
+def test_softmax_sum_kernels_vs_torch(B, T, K):
+    from sparch_amd._capi import check, lib, ptr
+
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = (torch.randn(B, T, K, generator=g) * 3).requires_grad_(True)
+    gy = torch.randn(B, K, generator=g)
+    ref = 0
+    for t in range(T):
+        ref = ref + torch.softmax(x[:, t, :], dim=-1)
+    ref.backward(gy)
+    xd = x.detach().to(DEV)
+    out = torch.empty(B, K, device=DEV)
+    dx = torch.empty(B, T, K, device=DEV)
+    check(lib.sparch_softmax_sum_fwd(B, T, K, ptr(xd), ptr(out), Fn._stream()), "softmax_sum_fwd")
+    check(lib.sparch_softmax_sum_bwd(B, T, K, ptr(xd), ptr(gy.to(DEV)), ptr(dx), Fn._stream()), "softmax_sum_bwd")
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-4, atol=1e-7)

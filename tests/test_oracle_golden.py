@@ -124,3 +124,39 @@ def test_draw_init_states_order_matches_reference_rng():
     for i, d in enumerate(st):
         for k, v in d.items():
             assert np.array_equal(v.numpy(), z[f"init.{i}.{k}"]), (i, k)
+
+
+# ------------------------------------------------------------------ f-4: non-spiking baselines (anns.py)
+ANN_CASES = ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout", "ann_RNN_bn", "ann_RNN_bidir", "ann_LiGRU_bn", "ann_GRU_bn"]
+
+
+@pytest.mark.parametrize("name", ANN_CASES)
+def test_ann_oracle_matches_reference_fixture(name):
+    """oracle/ann_oracle.py against outputs, loss, gradients, running statistics and the eval-mode output of
+    the real reference's ANN (tools/gen_golden.py)."""
+    import json
+
+    import torch.nn.functional as F
+
+    from oracle import ann_oracle as ao
+
+    z = load(name)
+    cfg = json.loads(str(z["cfg"]))
+    p = {k[len("param."):]: torch.tensor(z[k]).requires_grad_(z[k].dtype.kind == "f" and "running" not in k)
+         for k in z if k.startswith("param.") and "num_batches" not in k}
+    x, y = torch.tensor(z["x"]), torch.tensor(z["y"])
+    running = {k: v.detach().clone() for k, v in p.items() if "running" in k}
+    out = ao.ann_forward(cfg, p, x, training=True, running=running)
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=2e-5, atol=2e-6)
+    loss = F.cross_entropy(out, y) if cfg["use_readout_layer"] else (out * out).mean()
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=1e-5)
+    loss.backward()
+    for k in z:
+        if k.startswith("grad."):
+            g = p[k[len("grad."):]].grad
+            np.testing.assert_allclose(g.numpy(), z[k], rtol=2e-4, atol=2e-6, err_msg=k)
+        if k.startswith("after."):
+            np.testing.assert_allclose(running[k[len("after."):]].numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        out_e = ao.ann_forward(cfg, p, x, training=False, running=running)
+    np.testing.assert_allclose(out_e.numpy(), z["out_eval"], rtol=2e-5, atol=2e-6)

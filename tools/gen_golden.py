@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
+from sparch.models import anns as ref_ann  # noqa: E402  (the reference's non-spiking baselines, f-4)
 from sparch.models import snns as ref  # noqa: E402  (the reference)
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -177,6 +178,42 @@ def gen_snn(name, neuron_type, layer_sizes, B, T, C, *, normalization="batchnorm
          **{"param." + k: v for k, v in params0.items()}, **states, **grads, **stats1)
 
 
+def gen_ann(name, ann_type, layer_sizes, B, T, C, *, normalization="batchnorm", use_bias=False,
+            bidirectional=False, use_readout_layer=True, seed=4242):
+    """Non-spiking baselines (anns.py): MLP / RNN / LiGRU / GRU + ReadoutLayerANN.  No random initial state
+    (anns.py:331, 452, 584 start from zeros), dropout 0."""
+    torch.manual_seed(seed)
+    net = ref_ann.ANN(input_shape=(B, None, C), layer_sizes=layer_sizes, ann_type=ann_type, dropout=0.0,
+                      normalization=normalization, use_bias=use_bias, bidirectional=bidirectional,
+                      use_readout_layer=use_readout_layer)
+    with torch.no_grad():
+        for lay in net.ann:
+            if hasattr(lay, "norm"):
+                lay.norm.weight.uniform_(0.7, 1.3)
+                lay.norm.bias.uniform_(-0.2, 0.2)
+    gen = torch.Generator().manual_seed(999)
+    x = torch.randn(B, T, C, generator=gen)
+    n_cls = layer_sizes[-1]
+    y = torch.randint(0, n_cls, (B,), generator=gen)
+    params0 = {k: npy(v) for k, v in net.state_dict().items()}
+    net.train()
+    out, none = net(x)
+    assert none is None
+    loss = F.cross_entropy(out, y) if use_readout_layer else (out * out).mean()
+    loss.backward()
+    grads = {"grad." + k: npy(v.grad) for k, v in net.named_parameters()}
+    stats1 = {"after." + k: npy(v) for k, v in net.state_dict().items() if "running" in k}
+    net.eval()
+    with torch.no_grad():
+        out_e, _ = net(x)
+    save(name, x=npy(x), y=npy(y), out=npy(out), loss=npy(loss), out_eval=npy(out_e),
+         cfg=np.array(json.dumps(dict(ann_type=ann_type, layer_sizes=layer_sizes, B=B, T=T, C=C,
+                                      normalization=normalization, use_bias=use_bias,
+                                      bidirectional=bidirectional, use_readout_layer=use_readout_layer,
+                                      build_seed=seed))),
+         **{"param." + k: v for k, v in params0.items()}, **grads, **stats1)
+
+
 def gen_reference_checkpoint():
     """A whole-module pickle exactly as the reference writes it (torch.save(self.net, ...), exp.py:462),
     plus the eval-mode output it produces, to test that such checkpoints load through this repo's
@@ -218,6 +255,14 @@ def main():
     gen_snn("snn_LIF_noreadout", "LIF", [32, 24], 4, 20, 40,
             use_readout_layer=False, use_regularizers=False, p_in=0.2)
     gen_reference_checkpoint()
+    # f-4: non-spiking baselines
+    gen_ann("ann_MLP_bn", "MLP", [48, 48, 20], 6, 30, 40)
+    gen_ann("ann_MLP_ln_bias_noreadout", "MLP", [32, 24], 4, 20, 40, normalization="layernorm", use_bias=True,
+            use_readout_layer=False)
+    gen_ann("ann_RNN_bn", "RNN", [48, 48, 20], 6, 30, 40)
+    gen_ann("ann_RNN_bidir", "RNN", [32, 32, 20], 4, 24, 40, bidirectional=True, normalization="none")
+    gen_ann("ann_LiGRU_bn", "LiGRU", [32, 32, 20], 4, 24, 40)
+    gen_ann("ann_GRU_bn", "GRU", [32, 32, 20], 4, 24, 40)
 
 
 if __name__ == "__main__":
