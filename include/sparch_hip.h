@@ -213,6 +213,7 @@ int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
  *   steps_per_launch: T => one persistent launch per batch-tile group; 1 => one launch
  *           per time step (no inter-workgroup waiting at all; the safe fallback).     */
 size_t sparch_vpack_bytes(int H);
+/* transpose: bit 0 = pack V^T, bit 1 = keep the diagonal (dense cells of the ANN baselines) */
 int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked,
                  void* stream);
 size_t sparch_rec_chan_bytes(int Bp, int T, int H);
@@ -301,6 +302,26 @@ int sparch_act_bwd(int kind, size_t n, int H, const float* z, const float* scale
  * K % 4 == 0, K <= 4096.                                                                          */
 int sparch_softmax_sum_fwd(int B, int T, int K, const float* x, float* out, void* stream);
 int sparch_softmax_sum_bwd(int B, int T, int K, const float* x, const float* g, float* dx, void* stream);
+
+/* Dense recurrent cell of the RNN baseline (RNNLayer._rnn_cell, anns.py:328-339):
+ *     y_t = act(Wx_t * scale + shift + y_{t-1} V^T),  y_{-1} = 0          (forward)
+ *     dpre_t = (g_t + dpre_{t+1} V) * act'(y_t)                            (backward)
+ * The same persistent machine as sparch_rec_cell_bwd: V slice resident in registers, the previous step's
+ * dense fp32 tiles handed over through `chan` (sparch_rec_chan_bytes) and contracted on the bf16 MFMA
+ * with the exact six-term split.  vpack = sparch_vpack(H, V, transpose | 2, ...): bit 1 keeps the
+ * diagonal; forward uses transpose = 1 (y V^T), backward transpose = 0 (dpre V).
+ *   y_out   (B,T,H*dirs) dropout(y) with the directions concatenated on features (anns.py:319-324)
+ *   y_state (Bp,T,H)     y in cell time order: the backward's input
+ *   dpre    (Bp,T,H)     gradient w.r.t. the normalised projection, virtual rows, ORIGINAL time index
+ *   y_prev  (Bp,T,H)     y_{t-1} at the same index (zero row at the first step): dV = dpre^T y_prev      */
+int sparch_ann_rec_fwd(int act, int B, int dirs, int T, int H, const float* Wx, const float* scale,
+                       const float* shift, const float* vpack, float p_drop, uint64_t seed,
+                       float* y_out, float* y_state, void* chan, size_t chan_bytes, uint32_t* status,
+                       int steps_per_launch, void* stream);
+int sparch_ann_rec_bwd(int act, int B, int dirs, int T, int H, const float* g_out, const float* y_state,
+                       const float* vpack, float p_drop, uint64_t seed, float* dpre, float* y_prev,
+                       void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
+                       void* stream);
 
 /* ---- f-2: optimizer step on the device (replaces torch.optim.Adam.step, exp.py:89, 377) ----------
  * One launch for the whole parameter list; arithmetic identical, operation by operation, to

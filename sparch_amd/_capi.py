@@ -79,6 +79,10 @@ PROTOTYPES = {
     "sparch_act_bwd": (c_int, [c_int, c_size_t, c_int, P, P, P, P, c_float, c_uint64, P, P]),
     "sparch_softmax_sum_fwd": (c_int, [c_int, c_int, c_int, P, P, P]),
     "sparch_softmax_sum_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P]),
+    "sparch_ann_rec_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_uint64, P, P, P, c_size_t,
+                                   P, c_int, P]),
+    "sparch_ann_rec_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, c_uint64, P, P, P, c_size_t,
+                                   P, c_int, P]),
     "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

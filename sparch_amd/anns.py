@@ -5,9 +5,9 @@ Non-spiking baselines with the reference's module API (sparch/models/anns.py; SU
 constructor signatures, parameter names / shapes (state_dict keys) and the order of RNG draws at
 construction (anns.py:57-131, 173-208, 255-293, 367-410, 490-538, 617-642).  The arithmetic of MLP layers
 and of the readout runs in libsparch_hip.so (projection GEMMs on the exact bf16 split, BatchNorm folded
-into the activation kernel, softmax-sum readout); the recurrent baselines (RNN, LiGRU, GRU) are constructed
-and check-pointable but their forward is not implemented in this round and raises — there is no CPU
-fallback.
+into the activation kernel, softmax-sum readout) and so does the RNN baseline's cell (the persistent dense
+recurrent kernel, csrc/reccell.hip); the gated baselines (LiGRU, GRU) are constructed and check-pointable but
+their forward is not implemented in this round and raises — there is no CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -130,8 +130,21 @@ class _RecurrentANNLayer(_ANNLayer):
 
 
 class RNNLayer(_RecurrentANNLayer):
-    """anns.py:230-339 (constructor parity; forward pending)."""
+    """anns.py:230-339: y_t = sigmoid(norm(W x)_t + V y_{t-1}) on the persistent dense recurrent kernel."""
     KIND = "RNN"
+
+    def forward(self, x):
+        Fn._require_device(x, "input")
+        dirs = 2 if self.bidirectional else 1
+        rows = x.shape[0] * dirs
+        if self.batch_size != rows:
+            self.batch_size = rows
+        p_drop = float(self.dropout) if self.training else 0.0
+        nw, nb, rm, rv = self._norm_args()
+        cfg = {"act": "sigmoid", "normalization": self.normalization, "training": self.training, "dirs": dirs,
+               "p_drop": p_drop, "seed": self._dropout_seed(x.device) if p_drop > 0 else 0,
+               "running_mean": rm, "running_var": rv}
+        return Fn.RNNLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb, self.V.weight)
 
     def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
                  use_bias=False, bidirectional=False):

@@ -715,6 +715,241 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ dense recurrent cell (ANN baselines, f-4)
+// RNNLayer._rnn_cell (anns.py:328-339): y_t = act(Wx_t + y_{t-1} V^T), y_{-1} = 0, and its reverse pass
+//     dpre_t = (g_t + dpre_{t+1} V) * act'(y_t).
+// Both directions are the same machine as the spiking backward above: per step a workgroup contracts the
+// PREVIOUS step's dense fp32 row tile (handed over through the tagged ring, split exactly into three bf16
+// planes by the consumer) with its resident slice of V (six cross terms), then applies a pointwise rule and
+// publishes its own 32 x 32 tile.  `s` counts steps in processing order (forward: t = s, backward:
+// t = T-1-s); the tile of step s goes to ring slot s % RING with tag s + 1.
+struct AnnArgs {
+    int B, dirs, T, H, Bp;
+    int n_ct, nkg, n_rt_total;
+    int rt_base, n_rt_launch;
+    int s_begin, s_end;
+    const float* Wx; const float* scale; const float* shift;
+    const u32x4* vpack;
+    float p_drop, inv_keep; uint64_t seed;
+    float* y_state; float* y_out;                  // forward outputs
+    const float* g_out; const float* y_in;         // backward inputs (y_in = the forward's y_state)
+    float* dpre; float* y_prev;                    // backward outputs
+    unsigned* flags; char* ring; unsigned* status;
+};
+
+__device__ __forceinline__ float ann_act(int kind, float v) {
+    if (kind == SPARCH_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (kind == SPARCH_ACT_RELU) return fmaxf(v, 0.0f);
+    return tanhf(v);
+}
+__device__ __forceinline__ float ann_dact(int kind, float a) {  // through the activation's output
+    if (kind == SPARCH_ACT_SIGMOID) return a * (1.0f - a);
+    if (kind == SPARCH_ACT_RELU) return a > 0.0f ? 1.0f : 0.0f;
+    return 1.0f - a * a;
+}
+
+template <int ACT, bool BWD, int KGW, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
+    __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
+    __shared__ int abort_flag[2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const int rt = a.rt_base + (int)(blockIdx.x % a.n_rt_launch);
+    const int ct = (int)(blockIdx.x / a.n_rt_launch);
+    const int T = a.T, H = a.H, HO = a.H * a.dirs;
+
+    const bool pw = tid < 256;
+    const int r = (tid & 255) >> 3, cq = tid & 7;
+    const int bp = rt * RT + r, col = ct * CT + cq * 4;
+    const bool valid = pw && bp < a.Bp && col < H;
+    const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
+    const int d = bpc / a.B, b = bpc - d * a.B;
+
+    u32x4 vb[KGW][2][2];
+#pragma unroll
+    for (int kk = 0; kk < KGW; ++kk) {
+        const int kg = wave + NW * kk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4* src = a.vpack + ((((size_t)ct * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
+            vb[kk][ks][0] = src[0];
+            vb[kk][ks][1] = src[64];
+            vlo[wave][kk][ks][lane] = src[128];
+        }
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (!BWD && a.scale) { sc = ld4(a.scale + colc); sh = ld4(a.shift + colc); }
+    if (tid < 2) abort_flag[tid] = 0;
+    __syncthreads();
+
+    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * TILE_BYTES);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
+    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
+    const bool drop = a.p_drop > 0.0f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // per-step operands of the pointwise rule: forward x = Wx[b, tt]; backward g = g_out[b, tt, d*H..],
+    // y_t and y_{t-1} of this row in cell time
+    auto load_step = [&](int s, f32x4& v0, f32x4& v1, f32x4& v2) {
+        const int t = BWD ? (T - 1 - s) : s;
+        const int tt = d ? (T - 1 - t) : t;
+        if (!BWD) {
+            v0 = ld4(a.Wx + ((size_t)b * T + tt) * H + colc);
+        } else {
+            v0 = ld4(a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc);
+            v1 = ld4(a.y_in + ((size_t)bpc * T + t) * H + colc);
+            v2 = t > 0 ? ld4(a.y_in + ((size_t)bpc * T + (t - 1)) * H + colc) : zero4;
+        }
+    };
+    f32x4 n0 = zero4, n1 = zero4, n2 = zero4;
+    if (pw) load_step(a.s_begin, n0, n1, n2);
+
+    for (int s = a.s_begin; s < a.s_end; ++s) {
+        const f32x4 c0 = n0, c1 = n1, c2 = n2;
+        float rec[4] = {0.f, 0.f, 0.f, 0.f};
+        const int par = s & 1;
+        if (pw && s + 1 < a.s_end) load_step(s + 1, n0, n1, n2);
+
+        if (s > 0) {
+            const unsigned slot = (unsigned)((s - 1) % RING);
+            const unsigned want = (unsigned)s;
+            const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
+            if (wave == 0) {  // one polling wave, one 128-byte load per sweep (see rec_bwd_kernel)
+                const u64 t_start = __builtin_amdgcn_s_memrealtime();
+                const unsigned m = (lane < a.n_ct) ? 0xFFFFFFFFu : 0u;
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned tg = __hip_atomic_load(fl + min(lane, a.n_ct - 1), __ATOMIC_RELAXED, REC_LD_SCOPE);
+                    if (__all(((tg ^ want) & m) == 0)) break;
+                    if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                        raise_timeout(a.status, &abort_flag[par]);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (*(volatile int*)&abort_flag[par]) break;
+            const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
+            u32x4 raw[KGW][2][2];
+#pragma unroll
+            for (int kk = 0; kk < KGW; ++kk) {
+                const int kg = wave + NW * kk;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (kg < a.n_ct) {
+                            const unsigned off = base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024);
+                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
+                        } else {
+                            raw[kk][ks][q] = u32x4{0u, 0u, 0u, 0u};
+                        }
+                    }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KGW; ++kk) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 p1, p2, p3;  // exact truncation split of the 8 fp32 values
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const unsigned x0 = raw[kk][ks][q][2 * pr], x1 = raw[kk][ks][q][2 * pr + 1];
+                            const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
+                            const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
+                            const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                            const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                            const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                            p1[2 * q + pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                            p2[2 * q + pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                            p3[2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                        }
+                    const u32x4 vl = vlo[wave][kk][ks][lane];
+                    acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
+                    acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
+                    acc = mfma_bf16(p1, vl, acc);             // t1*lo
+                    acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
+                    acc = mfma_bf16(p1, vb[kk][ks][1], acc);  // t1*mid
+                    acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
+                }
+            }
+            float* rd = red[par][wave];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                rd[row * RED_LD + li] = acc[i];
+            }
+        }
+        __syncthreads();
+        if (*(volatile int*)&abort_flag[par]) break;
+        if (s > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = r * RED_LD + cq * 4 + e;
+                float sum = red[par][0][o];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum = sum + red[par][w][o];
+                rec[e] = sum;
+            }
+        }
+
+        // ---- pointwise rule
+        const int t = BWD ? (T - 1 - s) : s;
+        const int tt = d ? (T - 1 - t) : t;
+        const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
+        f32x4 val, aux;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+            if (!BWD) {
+                float xn = c0[e];
+                if (a.scale) xn = xn * sc[e] + sh[e];
+                const float y = ann_act(ACT, xn + rec[e]);                      // anns.py:336
+                val[e] = valid ? y : 0.0f;
+                aux[e] = y * k;                                                 // dropout after the cell (323-324)
+            } else {
+                const float dp = (c0[e] * k + rec[e]) * ann_dact(ACT, c1[e]);
+                val[e] = valid ? dp : 0.0f;
+                aux[e] = c2[e];
+            }
+        }
+        // ---- publish this step's tile (fragment order), write-through; drain; barrier; tag
+        if (pw && s + 1 < T) {
+            const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
+            const unsigned off = (unsigned)(s % RING) * slot_bytes + rt_off + (unsigned)ct * TILE_BYTES + piece;
+            u32x4 rawv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(val[e]);
+            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, REC_ST_AUX);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && s + 1 < T) {
+            gu32* f = (gu32*)a.flags + ((size_t)(s % RING) * a.n_rt_total + rt) * a.n_ct + ct;
+            __hip_atomic_store(f, (unsigned)(s + 1), __ATOMIC_RELAXED, REC_ST_SCOPE);
+        }
+        // ---- off the critical path: outputs
+        if (valid) {
+            if (!BWD) {
+                st4(a.y_state + ((size_t)bp * T + t) * H + col, val);
+                st4(a.y_out + ((size_t)b * T + tt) * HO + (size_t)d * H + col, aux);
+            } else {
+                st4(a.dpre + ((size_t)bp * T + tt) * H + col, val);
+                st4(a.y_prev + ((size_t)bp * T + tt) * H + col, aux);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ V prepack
 // vpack[ct][kg][ks][p][lane] = 8 bf16 (16 B): plane p (0 hi, 1 mid, 2 lo) of Vm[k][col] (forward) or
 // Vm[col][k] (backward) for k = kg*32 + 16*ks + 8*(lane>>5) + j, j = 0..7, col = ct*32 + (lane&31);
@@ -727,12 +962,13 @@ __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const floa
     const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 1);
     const int kg = (int)((idx >> 7) % nkg), ct = (int)((idx >> 7) / nkg);
     const int col = ct * 32 + (lane & 31);
+    const bool tr = transpose & 1, keep_diag = transpose & 2;  // bit 1: dense matrix of an ANN cell, no mask
     unsigned short pl[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
         float v = 0.f;
-        if (k < H && col < H && k != col) v = transpose ? V[(size_t)col * H + k] : V[(size_t)k * H + col];
+        if (k < H && col < H && (keep_diag || k != col)) v = tr ? V[(size_t)col * H + k] : V[(size_t)k * H + col];
         split3(v, pl[0][j], pl[1][j], pl[2][j]);
     }
 #pragma unroll
@@ -832,6 +1068,65 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
                 int rc = adapt ? launch_rec<true, true>(kgw, a, grid, st) : launch_rec<true, false>(kgw, a, grid, st);
                 if (rc != SPARCH_OK) return rc;
             }
+        }
+    }
+    return SPARCH_OK;
+}
+
+template <int ACT, bool BWD>
+int launch_ann(int kgw, const AnnArgs& a, unsigned grid, hipStream_t st) {
+#define SP_LAUNCH_ANN(KB, NWB) \
+    hipLaunchKernelGGL((ann_rec_kernel<ACT, BWD, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a);
+    switch (kgw) {
+        case 1: SP_LAUNCH_ANN(1, 4) break;
+        case 2: SP_LAUNCH_ANN(1, 8) break;
+        case 4: SP_LAUNCH_ANN(2, 8) break;
+        case 8: SP_LAUNCH_ANN(4, 8) break;
+        default: return SPARCH_EINVAL;
+    }
+#undef SP_LAUNCH_ANN
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+template <bool BWD>
+int run_ann(int act, AnnArgs& a, void* chan, size_t chan_bytes, int steps_per_launch, hipStream_t st) {
+    const int kgw = pick_kgw(a.H);
+    if (kgw == 0) return SPARCH_EINVAL;
+    a.n_ct = cdiv(a.H, CT);
+    a.nkg = 4 * kgw;
+    a.n_rt_total = cdiv(a.Bp, RT);
+    if (!chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
+    const size_t fb = bwd_flag_bytes(a.Bp, a.H);
+    if (hipMemsetAsync(chan, 0, fb, st) != hipSuccess) return SPARCH_ELAUNCH;
+    a.flags = reinterpret_cast<unsigned*>(chan);
+    a.ring = reinterpret_cast<char*>(chan) + fb;
+    int L = steps_per_launch;
+    if (L < 1) L = 1;
+    if (L > a.T) L = a.T;
+    int cus = sparch_device_cus();
+    if (cus <= 0) cus = 256;
+    int rt_per_launch;
+    if (L == 1) {
+        rt_per_launch = a.n_rt_total;
+    } else {
+        rt_per_launch = cus / a.n_ct;  // one workgroup per CU must be co-resident
+        if (rt_per_launch < 1) { L = 1; rt_per_launch = a.n_rt_total; }
+    }
+    for (int rt0 = 0; rt0 < a.n_rt_total; rt0 += rt_per_launch) {
+        a.rt_base = rt0;
+        a.n_rt_launch = min(rt_per_launch, a.n_rt_total - rt0);
+        const unsigned grid = (unsigned)(a.n_ct * a.n_rt_launch);
+        for (int s0 = 0; s0 < a.T; s0 += L) {
+            a.s_begin = s0; a.s_end = min(a.T, s0 + L);
+            int rc;
+            switch (act) {
+                case SPARCH_ACT_SIGMOID: rc = launch_ann<SPARCH_ACT_SIGMOID, BWD>(kgw, a, grid, st); break;
+                case SPARCH_ACT_RELU: rc = launch_ann<SPARCH_ACT_RELU, BWD>(kgw, a, grid, st); break;
+                case SPARCH_ACT_TANH: rc = launch_ann<SPARCH_ACT_TANH, BWD>(kgw, a, grid, st); break;
+                default: return SPARCH_EINVAL;
+            }
+            if (rc != SPARCH_OK) return rc;
         }
     }
     return SPARCH_OK;
@@ -942,4 +1237,40 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<true>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
+}
+
+// ---- f-4: dense recurrent cell of the RNN baseline (anns.py:328-339)
+extern "C" int sparch_ann_rec_fwd(int act, int B, int dirs, int T, int H, const float* Wx, const float* scale,
+                                  const float* shift, const float* vpack, float p_drop, uint64_t seed,
+                                  float* y_out, float* y_state, void* chan, size_t chan_bytes, uint32_t* status,
+                                  int steps_per_launch, void* stream) {
+    SPARCH_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4 != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
+    if (!Wx || !vpack || !y_out || !y_state || !status) return SPARCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({Wx, scale, shift, vpack, y_out, y_state, chan})) return SPARCH_EALIGN;
+    AnnArgs a{};
+    a.B = B; a.dirs = dirs; a.T = T; a.H = H; a.Bp = B * dirs;
+    a.Wx = Wx; a.scale = scale; a.shift = shift; a.vpack = reinterpret_cast<const u32x4*>(vpack);
+    a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    a.y_state = y_state; a.y_out = y_out; a.status = status;
+    return run_ann<false>(act, a, chan, chan_bytes, steps_per_launch, (hipStream_t)stream);
+}
+
+extern "C" int sparch_ann_rec_bwd(int act, int B, int dirs, int T, int H, const float* g_out, const float* y_state,
+                                  const float* vpack, float p_drop, uint64_t seed, float* dpre, float* y_prev,
+                                  void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
+                                  void* stream) {
+    SPARCH_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4 != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
+    if (!g_out || !y_state || !vpack || !dpre || !y_prev || !status) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({g_out, y_state, vpack, dpre, y_prev, chan})) return SPARCH_EALIGN;
+    AnnArgs a{};
+    a.B = B; a.dirs = dirs; a.T = T; a.H = H; a.Bp = B * dirs;
+    a.g_out = g_out; a.y_in = y_state; a.vpack = reinterpret_cast<const u32x4*>(vpack);
+    a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    a.dpre = dpre; a.y_prev = y_prev; a.status = status;
+    return run_ann<true>(act, a, chan, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }

@@ -721,3 +721,74 @@ class ReadoutANNFn(torch.autograd.Function):
             dx = torch.empty(B, T, K, dtype=torch.float32, device=x.device)
             check(lib.sparch_softmax_sum_bwd(B, T, K, ptr(x), ptr(gy), ptr(dx), _stream()), "sparch_softmax_sum_bwd")
         return None, dx, dW, dWb, dnw, dnb
+
+
+class RNNLayerFn(torch.autograd.Function):
+    """x (B,T,K) -> dropout(y) (B,T,H*dirs) with y_t = act(norm(W x)_t + y_{t-1} V^T): RNNLayer.forward,
+    anns.py:295-339.  The flipped copy of a bidirectional layer is never materialised (as for the spiking
+    layers: W(x.flip(1)) = W(x).flip(1), BatchNorm over B'T rows = over BT rows)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, W, Wb, nw, nb, V):
+        _require_device(x, "input")
+        _require_device(W, "layer parameters")
+        norm, training, dirs = cfg["normalization"], cfg["training"], cfg["dirs"]
+        x = _f32c(x)
+        B, T, K = x.shape
+        H = W.shape[0]
+        if H % 4 != 0 or H > 1024:
+            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0 and <= 1024")
+        M = B * T
+        dev = x.device
+        x2 = x.view(M, K)
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))             # anns.py:306
+        Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
+                                                    cfg.get("running_var"), training, dirs)          # 309-311
+        vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+        check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream()), "sparch_vpack")       # y V^T, dense
+        Bp = B * dirs
+        y_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
+        y_state = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        tok = timer.start("ann_rec_fwd[RNN]")
+        check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
+                                     ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state), ptr(chan),
+                                     nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+              "sparch_ann_rec_fwd")
+        timer.stop(tok)
+        ctx.cfg, ctx.shape, ctx.nsaved = cfg, (B, T, K, H), nsaved
+        ctx.save_for_backward(x2, W, nw, V, y_state, Wx_raw if norm in ("batchnorm", "layernorm") else None)
+        return y_out
+
+    @staticmethod
+    def backward(ctx, g_y):
+        cfg = ctx.cfg
+        norm, dirs = cfg["normalization"], cfg["dirs"]
+        B, T, K, H = ctx.shape
+        x2, W, nw, V, y_state, Wx_raw = ctx.saved_tensors
+        M, Bp = B * T, B * dirs
+        dev = x2.device
+        vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+        check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream()), "sparch_vpack")       # dpre V, dense
+        dpre = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+        y_prev = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
+        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        tok = timer.start("ann_rec_bwd[RNN]")
+        check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(vpack),
+                                     cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
+                                     ptr(status_word(dev)), rec_steps_per_launch(T), _stream()), "sparch_ann_rec_bwd")
+        timer.stop(tok)
+        # dV[i][j] = sum over rows and steps of dpre[.,i] * y_{t-1}[.,j]   (V(y) = y V^T, anns.py:336)
+        dV = gemm_tn(dpre.view(Bp * T, H), y_prev.view(Bp * T, H))
+        if dirs == 2:  # both directions share the projection rows (anns.py:298-300)
+            dy = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+            check(lib.sparch_add_halves(M * H, ptr(dpre), ptr(dy), _stream()), "sparch_add_halves")
+        else:
+            dy = dpre
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy.view(M, H), Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dW = gemm_tn(dx_raw, x2)
+        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
+        dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
+        return None, dx, dW, dWb, dnw, dnb, dV

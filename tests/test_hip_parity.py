@@ -785,7 +785,7 @@ def _ann_from_fixture(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout"])
+@pytest.mark.parametrize("name", ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout", "ann_RNN_bn", "ann_RNN_bidir"])
 def test_mlp_ann_matches_reference_fixture(name):
     """The MLP baseline + ANN readout on the HIP path against the real reference's outputs, loss, gradients,
     running statistics and eval-mode output (tests/golden/ann_MLP_*.npz).  fp32 tolerance, relative to each
@@ -876,3 +876,70 @@ def test_softmax_sum_kernels_vs_torch(B, T, K):
     check(lib.sparch_softmax_sum_bwd(B, T, K, ptr(xd), ptr(gy.to(DEV)), ptr(dx), Fn._stream()), "softmax_sum_bwd")
     torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bidir,H", [(False, 256), (True, 128)])
+def test_rnn_layer_vs_oracle_larger_and_chunked(bidir, H, monkeypatch):
+    """RNN baseline layer on shapes with several row tiles and k-groups per wave, against the CPU oracle
+    (oracle/ann_oracle.py, pinned to the reference); one persistent launch, 7-step chunks and one launch per
+    step must agree BIT FOR BIT (same arithmetic, only the launch boundaries move)."""
+    from oracle import ann_oracle as ao
+    from sparch_amd.anns import RNNLayer
+
+    B, T, C = 40, 23, 64
+    torch.manual_seed(17)
+    layer = RNNLayer(C, H, B, dropout=0.0, normalization="batchnorm", use_bias=True, bidirectional=bidir)
+    with torch.no_grad():
+        layer.norm.weight.uniform_(0.7, 1.3)
+        layer.norm.bias.uniform_(-0.2, 0.2)
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(B, T, C, generator=g)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g)
+    p = {"ann.0." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+         for k, v in layer.state_dict().items() if "num_batches" not in k}
+    xr = x.clone().requires_grad_(True)
+    ref = ao.hidden_layer("RNN", xr, p, "ann.0", "batchnorm", bidir, training=True, running=None)
+    (ref * gy).sum().backward()
+    layer = layer.to(DEV).train()
+    outs = []
+    for spl in ("", "7", "1"):
+        monkeypatch.setenv("SPARCH_REC_STEPS_PER_LAUNCH", spl)
+        layer.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        y = layer(xd)
+        (y * gy.to(DEV)).sum().backward()
+        _Fn().check_status()
+        outs.append((y.detach().cpu(), xd.grad.cpu(), {k: v.grad.cpu() for k, v in layer.named_parameters()}))
+    y0, dx0, g0 = outs[0]
+    assert relmax(y0.numpy(), ref.detach().numpy()) <= 2e-5
+    assert relmax(dx0.numpy(), xr.grad.numpy()) <= 2e-4
+    for k, v in g0.items():
+        if k == "W.bias":  # BatchNorm removes the column mean: this gradient is exactly zero in real arithmetic
+            assert np.abs(v.numpy() - p["ann.0." + k].grad.numpy()).max() <= 1e-4 * float(g0["W.weight"].abs().max())
+            continue
+        assert relmax(v.numpy(), p["ann.0." + k].grad.numpy()) <= 2e-4, k
+    for y1, dx1, g1 in outs[1:]:
+        assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.gpu
+def test_rnn_layer_dropout_is_applied_after_the_cell():
+    """anns.py:323-324: dropout acts on the layer output only; the recurrent state stays un-dropped, so the
+    kept entries equal the no-dropout output scaled by 1/(1-p)."""
+    from sparch_amd.anns import RNNLayer
+
+    torch.manual_seed(5)
+    layer = RNNLayer(32, 64, 8, dropout=0.3, normalization="none").to(DEV)
+    x = torch.randn(8, 15, 32, generator=torch.Generator().manual_seed(6)).to(DEV)
+    layer.eval()
+    with torch.no_grad():
+        y_ref = layer(x).cpu()
+    layer.train()
+    with torch.no_grad():
+        y = layer(x).cpu()
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.7) < 0.03
+    torch.testing.assert_close(y[kept], (y_ref / 0.7)[kept], rtol=1e-6, atol=1e-7)
