@@ -38,6 +38,9 @@ WORKLOADS = {
     "cfg3": dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
     # BASELINE.json configs[1]: adLIF 3x512 on SHD shapes (HBM-bound fused cell kernels); informational
     "cfg2": dict(neuron_type="adLIF", layer_sizes=[512, 512, 20], B=128, T=250, C=700, pdrop=0.1),
+    # SURVEY f-4: the reference's non-spiking baselines at the headline shape; informational
+    "rnn": dict(neuron_type="RNN", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
+    "mlp": dict(neuron_type="MLP", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
 }
 WORKLOAD = WORKLOADS["cfg3"]
 
@@ -48,7 +51,7 @@ def algorithmic_work(name, B, T, H):
     if m:
         M, N, K = int(m.group(2)), int(m.group(3)), int(m.group(4))
         return "mfma", 2.0 * M * N * K, "flop"
-    if name.startswith("rec_cell_fwd") or name.startswith("rec_cell_bwd"):
+    if name.startswith("rec_cell_fwd") or name.startswith("rec_cell_bwd") or name.startswith("ann_rec_"):
         # one (B x H) x (H x H) recurrent product per time step (s_{t-1} V  or  dWx_{t+1} V^T)
         return "mfma", 2.0 * B * H * H * T, "flop"
     if name.startswith("cell_fwd") or name.startswith("cell_bwd"):
@@ -156,8 +159,13 @@ def main():
     w = WORKLOAD
     B, T, C, H = w["B"], w["T"], w["C"], w["layer_sizes"][0]
     torch.manual_seed(1234)
-    net = sparch_amd.SNN((B, None, C), w["layer_sizes"], neuron_type=w["neuron_type"], dropout=w["pdrop"],
-                         normalization="batchnorm").to(dev)
+    if w["neuron_type"] in ("RNN", "MLP"):
+        from sparch_amd.anns import ANN
+        net = ANN((B, None, C), w["layer_sizes"], ann_type=w["neuron_type"], dropout=w["pdrop"],
+                  normalization="batchnorm").to(dev)
+    else:
+        net = sparch_amd.SNN((B, None, C), w["layer_sizes"], neuron_type=w["neuron_type"], dropout=w["pdrop"],
+                             normalization="batchnorm").to(dev)
     net.train()
     opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)  # exp.py:89 (same arithmetic, one launch: SURVEY f-2)
     loss_fn = torch.nn.CrossEntropyLoss()           # exp.py:100
@@ -228,7 +236,8 @@ def main():
             cpu = cpu_baseline(rank)
         line = {
             "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " +
-                      ("RadLIF 3x1024 SSC shape" if args.workload == "cfg3" else "adLIF 3x512 SHD shape"),
+                      {"cfg3": "RadLIF 3x1024 SSC shape", "cfg2": "adLIF 3x512 SHD shape",
+                       "rnn": "RNN baseline 3x1024 SSC shape", "mlp": "MLP baseline 3x1024 SSC shape"}[args.workload],
             "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -21,14 +21,15 @@ import torch.distributed as dist
 
 class GradAllReducer:
     def __init__(self, module, process_group=None, buckets=None):
-        """buckets: list of lists of parameters (default: one bucket per child of `module.snn`,
+        """buckets: list of lists of parameters (default: one bucket per child of `module.snn` / `module.ann`,
         or a single bucket for arbitrary modules).  Buckets fire in whatever order backward
         completes them (readout first, input layer last)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if buckets is None:
-            if hasattr(module, "snn"):
-                buckets = [[p for p in layer.parameters() if p.requires_grad] for layer in module.snn]
+            layers = getattr(module, "snn", None) or getattr(module, "ann", None)  # SNN / ANN layer lists
+            if layers is not None:
+                buckets = [[p for p in layer.parameters() if p.requires_grad] for layer in layers]
             else:
                 buckets = [[p for p in module.parameters() if p.requires_grad]]
         self.buckets = [b for b in buckets if b]
