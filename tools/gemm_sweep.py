@@ -1,3 +1,4 @@
+"""Diagnostic: wall time of the headline TN GEMM shapes (spike x dense both ways, dense x dense)."""
 import sys, torch
 sys.path.insert(0, ".")
 from sparch_amd import functional as Fn
