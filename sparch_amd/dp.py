@@ -65,7 +65,9 @@ class GradAllReducer:
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        """Wait for every bucket, write the mean back into .grad, re-arm for the next step."""
+        """Wait for every bucket, turn the sums into means and hand them to the optimizer, re-arm for the
+        next step.  The averaged gradients stay in the flat bucket: each `.grad` becomes a view of it (one
+        scaling kernel per bucket, no copy back)."""
         if self.world > 1:
             inv = 1.0 / self.world
             for bi, bucket in enumerate(self.buckets):
@@ -76,10 +78,11 @@ class GradAllReducer:
                         continue  # layer took no part in this backward
                 self._work[bi].wait()
                 flat = self._flat[bi]
+                flat.mul_(inv)
                 off = 0
                 for p in bucket:
                     n = p.numel()
-                    p.grad.copy_(flat[off:off + n].view_as(p.grad) * inv)
+                    p.grad = flat[off:off + n].view_as(p)
                     off += n
         self.reset()
 
