@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libsparch_hip.so (it is git-ignored): build it once, as
+    __graft_entry__.build() does.  hipcc cross-compiles gfx950 without a GPU.  (This is a build step, not a
+    fallback: with no library the package refuses to import.)"""
+    lib = os.path.join(ROOT, "sparch_amd", "libsparch_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "sparch_amd", "csrc")], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
 def _has_gpu():
     try:
         import torch
