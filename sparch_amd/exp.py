@@ -8,7 +8,8 @@ checkpointing as a whole-module pickle (456-463, 126-133).
 The training step itself (exp.py:352-382) runs on the MI355X path: `sparch_amd.SNN` on a HIP device.
 What this build adds, not replaces:
   * --synthetic 1: batches of the dataset's shape generated on the fly (no SHD/SSC/HD/SC files exist
-    offline; the h5py / torchaudio loaders of the reference are out of scope this round);
+    offline); without it SHD/SSC go through sparch_amd.dataloaders (h5py event lists binned on the device),
+    HD/SC (torchaudio files) are not covered;
   * hd / sc inputs are raw waveforms turned into 40-bin log-mel features ON THE DEVICE by
     `sparch_amd.fbank` (the reference calls torchaudio's kaldi.fbank per clip on the CPU,
     nonspiking_datasets.py:96, 194);
@@ -175,13 +176,27 @@ class Experiment:
         else:
             raise ValueError(f"Invalid dataset name {self.dataset_name}")
         self.input_kind = kind
-        if not self.synthetic:
-            raise RuntimeError(
-                "sparch_amd: the file-based SHD/SSC (h5py) and HD/SC (torchaudio) loaders of the reference are not "
-                "part of this build yet (no dataset files or those packages offline); run with --synthetic 1")
         if self.batch_size % self.world != 0:
             raise ValueError(f"batch_size {self.batch_size} must be divisible by the number of GPUs {self.world}")
         per_rank = self.batch_size // self.world
+        if not self.synthetic:
+            if kind != "spiking":
+                raise RuntimeError(
+                    "sparch_amd: the file-based HD/SC (torchaudio) loader of the reference is not part of this "
+                    "build (no torchaudio offline); run with --synthetic 1")
+            if self.world > 1:
+                raise RuntimeError("sparch_amd: file-based datasets are single-process in this round "
+                                   "(no per-rank sampler yet); use --synthetic 1 for data-parallel runs")
+            from .dataloaders.spiking_datasets import load_shd_or_ssc  # exp.py:224-252 (needs h5py + the files)
+
+            def ld(split, shuffle):
+                return load_shd_or_ssc(self.dataset_name, self.data_folder, split, per_rank, nb_steps=100,
+                                       shuffle=shuffle, device=self.device)
+
+            self.train_loader, self.valid_loader = ld("train", True), ld("valid", False)
+            if self.dataset_name == "ssc":
+                self.test_loader = ld("test", False)
+            return
 
         def mk(seed):
             return _SyntheticLoader(kind, per_rank, self.synthetic_batches, self.nb_outputs, self.seq_len,

@@ -1009,3 +1009,27 @@ def test_full_size_cfg_bidirectional_long_sequence(sp):
             assert float(torch.diag(v.grad).abs().max()) == 0.0
     assert bool(torch.isfinite(net.snn[3].alpha.grad).all())  # the readout has no adaptation state
     assert tuple(net.snn[1].W.weight.shape) == (1024, 2048)  # hidden input doubles (snns.py:140)
+
+
+@pytest.mark.gpu
+def test_shd_ssc_loader_batches_binned_on_device():
+    """sparch_amd.dataloaders.load_shd_or_ssc on an in-memory stand-in for the h5 file: every batch equals the
+    reference's per-sample np.digitize + sparse->dense (oracle/events_numpy.py) bit for bit, and keeps the
+    (x, xlens, y) collate contract (spiking_datasets.py:80-87)."""
+    from oracle import events_numpy as ev
+    from sparch_amd.dataloaders.spiking_datasets import load_shd_or_ssc
+    from tests.test_host import _fake_h5
+
+    h5 = _fake_h5(n=11)
+    loader = load_shd_or_ssc("shd", "/unused", "valid", batch_size=4, shuffle=False, h5_file=h5, device=DEV)
+    seen = 0
+    for xs, xlens, ys in loader:
+        b = xs.shape[0]
+        assert xs.device.type == "cuda" and tuple(xs.shape[1:]) == (100, 700) and xs.dtype == torch.float32
+        assert xlens.tolist() == [100] * b and ys.dtype == torch.int64
+        for j in range(b):
+            ref, _ = ev.bin_sample(h5["spikes"]["times"][seen + j], h5["spikes"]["units"][seen + j])
+            np.testing.assert_array_equal(xs[j].cpu().numpy(), ref)
+            assert int(ys[j]) == int(h5["labels"][seen + j])
+        seen += b
+    assert seen == 11

@@ -106,3 +106,46 @@ def test_ann_construction_matches_reference_rng_and_keys(name):
         ANN((4, None, 8), [8, 4], ann_type="LSTM")
     with pytest.raises(ValueError):
         ANN((4, None, 8), [8, 4], ann_type="MLP", bidirectional=True)
+
+
+# ------------------------------------------------------------------ f-3: SHD / SSC loader API
+def _fake_h5(n=11, seed=3):
+    rng = np.random.default_rng(seed)
+    times, units = [], []
+    for i in range(n):
+        m = int(rng.integers(0, 400)) if i != 4 else 0          # one empty sample
+        t = np.sort(rng.uniform(0.0, 1.39, m)).astype(np.float32)
+        if m > 3:
+            t[:2] = 0.0                                           # exactly on the first edge
+        times.append(t)
+        units.append(rng.integers(0, 700, m).astype(np.int32))
+    return {"spikes": {"times": times, "units": units}, "labels": rng.integers(0, 20, n)}
+
+
+def test_spiking_dataset_api_and_errors():
+    from sparch_amd.dataloaders.spiking_datasets import SpikingDataset, load_shd_or_ssc
+    from oracle import events_numpy as ev
+
+    with pytest.raises(ValueError):
+        load_shd_or_ssc("mnist", "/x", "train", 4)
+    with pytest.raises(ValueError):
+        load_shd_or_ssc("shd", "/x", "dev", 4)
+    with pytest.raises(ValueError):
+        load_shd_or_ssc("shd", "/x", "train", 4, workers=2, h5_file=_fake_h5())
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            SpikingDataset("shd", "/nonexistent", "train")
+    ds = SpikingDataset("ssc", "/unused", "valid", nb_steps=100, h5_file=_fake_h5(), device="cpu")
+    assert len(ds) == 11 and ds.nb_units == 700 and ds.max_time == 1.4
+    t, u, y = ds[2]
+    assert t.dtype == np.float32 and u.dtype == np.int32 and isinstance(y, int)
+    # dense_sample restates the reference's __getitem__ (spiking_datasets.py:66-78): check against the oracle
+    for i in (0, 2, 4):
+        x, yy = ds.dense_sample(i)
+        np.testing.assert_array_equal(x.numpy(), ev.bin_sample(ds.firing_times[i], ds.units_fired[i])[0])
+        assert yy == int(ds.labels[i])
+    # the import path of the reference resolves to the same classes
+    from sparch.dataloaders.spiking_datasets import SpikingDataset as S2
+    assert S2 is SpikingDataset
