@@ -18,7 +18,9 @@
 //     exact products and fp32 accumulation: same accuracy class as an fp32 fmaf chain at 3/16
 //     of its cost.  In the backward dWx is split as well (x = t1 + t2 + t3 exactly) and the six
 //     largest cross terms (t1*hi, t1*mid, t2*hi, t1*lo, t3*hi, t2*mid; the dropped ones are
-//     <= 2^-25 relative each) are accumulated: fp32-faithful at 6/16 of the fp32 MFMA cost;
+//     t3*mid <= 2^-22 and t2*lo <= 2^-23 of |x||V| per product in the worst case; measured aggregate
+//     3e-9 of sum|x||V| against 1e-7 for an fp32 sgemm's own rounding) are accumulated: fp32-faithful
+//     at 6/16 of the fp32 MFMA cost;
 //   * the 32 workgroups of one batch tile exchange the step's output every step:
 //       forward  — spikes, bit-packed, as 8-byte {tag = t+1, 32 spike bits} granules written
 //                  with one agent-scope (sc1, write-through) store each and polled with sc1
@@ -589,8 +591,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                             }
                         const u32x4 vl = vlo[wave][kk][ks][lane];
                         // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first.  Dropped:
-                        // t3*mid, t2*lo (<= 2^-25 relative each: |t3| < 2^-16 |x| after two 8-bit truncations,
-                        // |V_mid| <= 2^-9 |V|) and t3*lo — the same cut as the dense 6-term GEMM.
+                        // t3*mid (|t3| < 2^-14 |x| after two 8-bit truncations, |V_mid| <= 2^-8 |V|: <= 2^-22 of
+                        // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
+                        // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
+                        // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
                         acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
                         acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
                         acc = mfma_bf16(p1, vl, acc);             // t1*lo
