@@ -99,8 +99,8 @@ int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const vo
                            int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* Dense x dense products on the same exact-split machinery: BOTH fp32 operands are split into three
- * bf16 planes and the six cross terms >= 2^-16 relative are accumulated in fp32 (dropped terms
- * <= 2^-24): fp32-faithful results at 6/16 of the fp32-MFMA cost.  Same argument meaning as
+ * bf16 planes and the six largest cross terms are accumulated in fp32 (the rest measures ~1e-8 of
+ * sum|a||b|, below an fp32 sgemm's own rounding): fp32-faithful results at 6/16 of the fp32-MFMA cost.  Same argument meaning as
  * sparch_gemm_nt / _nn / _tn (the tn workspace is sparch_gemm_spike_tn_workspace_bytes).          */
 int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, float* colstat_ws, void* stream);
