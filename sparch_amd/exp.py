@@ -58,7 +58,13 @@ class _SyntheticLoader:
         for _ in range(self.n_batches):
             y = torch.randint(0, self.n_classes, (self.batch_size,), generator=g)
             if self.kind == "spiking":
-                x = (torch.rand(self.batch_size, self.seq_len, 700, generator=g) < 0.05).float()
+                # class-dependent input: a band of 700 // n_classes channels fires at 0.25 instead of 0.04,
+                # so that a run on synthetic data has something to learn (labels are not independent of x)
+                band = 700 // self.n_classes
+                ch = torch.arange(700)[None, :]
+                hot = (ch >= y[:, None] * band) & (ch < (y[:, None] + 1) * band)
+                rate = torch.where(hot, torch.tensor(0.25), torch.tensor(0.04))[:, None, :]
+                x = (torch.rand(self.batch_size, self.seq_len, 700, generator=g) < rate).float()
                 xlens = torch.full((self.batch_size,), self.seq_len)
             else:
                 t = torch.arange(16000) / 16000.0

@@ -1033,3 +1033,35 @@ def test_shd_ssc_loader_batches_binned_on_device():
             assert int(ys[j]) == int(h5["labels"][seen + j])
         seen += b
     assert seen == 11
+
+
+@pytest.mark.parametrize("neuron_type", ["LIF", "RadLIF"])
+def test_training_learns_class_conditional_synthetic_task(sp, neuron_type):
+    """End to end: forward + CE on the softmax-sum + backward + one-launch Adam (exp.py:359-377) on the
+    synthetic SHD-shaped task whose labels select a band of input channels.  Gradient parity is checked
+    elsewhere; this checks that the pieces train: held-out accuracy far above chance (1/20) after 60 steps."""
+    from sparch_amd.exp import _SyntheticLoader
+    from sparch_amd.optim import Adam
+
+    B, T = 64, 50
+    torch.manual_seed(3)
+    net = sp.SNN((B, None, 700), [128, 128, 20], neuron_type=neuron_type, dropout=0.1).to(DEV).train()
+    opt = Adam(net.parameters(), 1e-2)
+    first = None
+    for x, _, y in _SyntheticLoader("spiking", B, 60, 20, T, seed=11):
+        out, rates = net(x.to(DEV))
+        loss = torch.nn.functional.cross_entropy(out, y.to(DEV))
+        first = float(loss.detach()) if first is None else first
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    _Fn().check_status()
+    net.eval()
+    hits = n = 0
+    with torch.no_grad():
+        for x, _, y in _SyntheticLoader("spiking", B, 4, 20, T, seed=12):
+            out, _ = net(x.to(DEV))
+            hits += int((out.argmax(1).cpu() == y).sum())
+            n += B
+    assert float(loss.detach()) < 0.7 * first, (first, float(loss.detach()))
+    assert hits / n > 0.6, hits / n
