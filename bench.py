@@ -41,6 +41,8 @@ WORKLOADS = {
     # SURVEY f-4: the reference's non-spiking baselines at the headline shape; informational
     "rnn": dict(neuron_type="RNN", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
     "mlp": dict(neuron_type="MLP", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
+    "ligru": dict(neuron_type="LiGRU", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
+    "gru": dict(neuron_type="GRU", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
 }
 WORKLOAD = WORKLOADS["cfg3"]
 
@@ -159,7 +161,7 @@ def main():
     w = WORKLOAD
     B, T, C, H = w["B"], w["T"], w["C"], w["layer_sizes"][0]
     torch.manual_seed(1234)
-    if w["neuron_type"] in ("RNN", "MLP"):
+    if w["neuron_type"] in ("RNN", "MLP", "LiGRU", "GRU"):
         from sparch_amd.anns import ANN
         net = ANN((B, None, C), w["layer_sizes"], ann_type=w["neuron_type"], dropout=w["pdrop"],
                   normalization="batchnorm").to(dev)
@@ -237,7 +239,8 @@ def main():
         line = {
             "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " +
                       {"cfg3": "RadLIF 3x1024 SSC shape", "cfg2": "adLIF 3x512 SHD shape",
-                       "rnn": "RNN baseline 3x1024 SSC shape", "mlp": "MLP baseline 3x1024 SSC shape"}[args.workload],
+                       "rnn": "RNN baseline 3x1024 SSC shape", "mlp": "MLP baseline 3x1024 SSC shape",
+                       "ligru": "LiGRU baseline 3x1024 SSC shape", "gru": "GRU baseline 3x1024 SSC shape"}[args.workload],
             "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -323,6 +323,18 @@ int sparch_ann_rec_bwd(int act, int B, int dirs, int T, int H, const float* g_ou
                        void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
                        void* stream);
 
+/* Gate arithmetic of ONE time step of the gated baselines (LiGRULayer._ligru_cell anns.py:449-462,
+ * GRULayer._gru_cell anns.py:581-595); the recurrent products between the phases are GEMM calls.  This
+ * round these cells run launch-per-step (see annstep.hip).  mode: 0 LiGRU forward, 1 GRU forward gates
+ * (z, r, r*y), 2 GRU forward candidate + state, 3 LiGRU backward, 4 GRU backward (dy, dz_pre, dc_pre),
+ * 5 GRU backward (dr_pre).  `in` / `out` are HOST arrays of 14 device pointers each (unused slots NULL):
+ *   in : Wx sc sh Wzx scz shz Wrx scr shr rec g_out carry_mv carry_dir dry
+ *   out: y_state z_save r_save c_save ry y_out carry_dir_out dgate dcp dz_all dr_all dc_all yprev_all ry_all
+ * Shapes: projections (B,T,H) with folded BatchNorm (H) each; rec (Bp,2H) or (Bp,H); saves (Bp,T,H) in cell
+ * time order; *_all (Bp,T,H) at the original time index; y_out / g_out (B,T,H*dirs).  H % 4 == 0.      */
+int sparch_gate_step(int mode, int B, int dirs, int T, int H, int t, const float* const* in,
+                     float* const* out, float p_drop, uint64_t seed, void* stream);
+
 /* ---- f-2: optimizer step on the device (replaces torch.optim.Adam.step, exp.py:89, 377) ----------
  * One launch for the whole parameter list; arithmetic identical, operation by operation, to
  * torch.optim.Adam's default path (see optim.hip).  `params`, `grads`, `exp_avg`, `exp_avg_sq` are HOST

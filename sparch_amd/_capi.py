@@ -83,6 +83,7 @@ PROTOTYPES = {
                                    P, c_int, P]),
     "sparch_ann_rec_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, c_uint64, P, P, P, c_size_t,
                                    P, c_int, P]),
+    "sparch_gate_step": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, c_uint64, P]),
     "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

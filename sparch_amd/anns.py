@@ -6,8 +6,9 @@ constructor signatures, parameter names / shapes (state_dict keys) and the order
 construction (anns.py:57-131, 173-208, 255-293, 367-410, 490-538, 617-642).  The arithmetic of MLP layers
 and of the readout runs in libsparch_hip.so (projection GEMMs on the exact bf16 split, BatchNorm folded
 into the activation kernel, softmax-sum readout) and so does the RNN baseline's cell (the persistent dense
-recurrent kernel, csrc/reccell.hip); the gated baselines (LiGRU, GRU) are constructed and check-pointable but
-their forward is not implemented in this round and raises — there is no CPU fallback.
+recurrent kernel, csrc/reccell.hip); the gated baselines (LiGRU, GRU) run launch-per-step this round: a host
+loop over time with the recurrent products on the library's GEMMs and the gate arithmetic in
+`sparch_gate_step` (csrc/annstep.hip) — correct, not yet a performance path.  No CPU fallback anywhere.
 """
 import torch
 import torch.nn as nn
@@ -124,9 +125,24 @@ class _RecurrentANNLayer(_ANNLayer):
     KIND = None
 
     def forward(self, x):
-        raise NotImplementedError(
-            f"sparch_amd: the {self.KIND} baseline's recurrent cell has no HIP kernel in this round "
-            "(SURVEY.md §8 f-4); MLP and the ANN readout do")
+        """LiGRU / GRU (anns.py:412-447, 540-579): launch-per-step on the HIP kernels (functional.GatedLayerFn)."""
+        Fn._require_device(x, "input")
+        dirs = 2 if self.bidirectional else 1
+        rows = x.shape[0] * dirs
+        if self.batch_size != rows:
+            self.batch_size = rows
+        p_drop = float(self.dropout) if self.training else 0.0
+        mats = ("c", "z", "r") if self.KIND == "GRU" else ("c", "z")
+        suffix = {"c": "", "z": "z", "r": "r"}
+        params, running = [], {}
+        for m in mats:
+            W, V = getattr(self, "W" + suffix[m]), getattr(self, "V" + suffix[m])
+            nw, nb, rm, rv = self._norm_args("norm" + suffix[m])
+            params += [W.weight, W.bias, nw, nb, V.weight]
+            running[m] = (rm, rv)
+        cfg = {"kind": self.KIND, "normalization": self.normalization, "training": self.training, "dirs": dirs,
+               "p_drop": p_drop, "seed": self._dropout_seed(x.device) if p_drop > 0 else 0, "running": running}
+        return Fn.GatedLayerFn.apply(cfg, x, *params)
 
 
 class RNNLayer(_RecurrentANNLayer):
@@ -166,7 +182,7 @@ class RNNLayer(_RecurrentANNLayer):
 
 
 class LiGRULayer(_RecurrentANNLayer):
-    """anns.py:342-462 (constructor parity; forward pending)."""
+    """anns.py:342-462: z = sigmoid(.), c = relu(.), y = z y + (1-z) c; launch-per-step this round."""
     KIND = "LiGRU"
 
     def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
@@ -194,7 +210,7 @@ class LiGRULayer(_RecurrentANNLayer):
 
 
 class GRULayer(_RecurrentANNLayer):
-    """anns.py:465-595 (constructor parity; forward pending)."""
+    """anns.py:465-595: z, r = sigmoid(.), c = tanh(W x + V (r y)), y = z y + (1-z) c; launch-per-step this round."""
     KIND = "GRU"
 
     def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",

@@ -224,8 +224,8 @@ class Experiment:
                            bidirectional=self.bidirectional, use_readout_layer=True).to(self.device)
             logging.info(f"\nCreated new spiking model:\n {self.net}\n")
         elif self.model_type in ["MLP", "RNN", "LiGRU", "GRU"]:
-            # exp.py:311-322.  MLP runs on the HIP path; the recurrent baselines construct (checkpoints,
-            # parameter counts) but their forward raises (pending).
+            # exp.py:311-322: MLP and RNN on the fused / persistent kernels, LiGRU and GRU
+            # launch-per-step
             self.net = ANN(input_shape=input_shape, layer_sizes=layer_sizes, ann_type=self.model_type,
                            dropout=self.pdrop, normalization=self.normalization, use_bias=self.use_bias,
                            bidirectional=self.bidirectional, use_readout_layer=True).to(self.device)

@@ -9,6 +9,7 @@ device memory, the stream and the autograd graph edges between layers.
 
 No CPU fallback: CPU tensors raise.
 """
+import ctypes
 import os
 
 import torch
@@ -792,3 +793,135 @@ class RNNLayerFn(torch.autograd.Function):
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
         return None, dx, dW, dWb, dnw, dnb, dV
+
+
+def _gate_step(mode, B, dirs, T, H, t, ins, outs, p_drop, seed):
+    """One launch of sparch_gate_step; ins / outs: dicts slot name -> tensor (missing = NULL)."""
+    in_names = ["Wx", "sc", "sh", "Wzx", "scz", "shz", "Wrx", "scr", "shr", "rec", "g_out", "carry_mv", "carry_dir", "dry"]
+    out_names = ["y_state", "z_save", "r_save", "c_save", "ry", "y_out", "carry_dir_out", "dgate", "dcp", "dz_all",
+                 "dr_all", "dc_all", "yprev_all", "ry_all"]
+    arr = ctypes.c_void_p * 14
+    a_in = arr(*[(ins[n].data_ptr() if ins.get(n) is not None else None) for n in in_names])
+    a_out = arr(*[(outs[n].data_ptr() if outs.get(n) is not None else None) for n in out_names])
+    check(lib.sparch_gate_step(mode, B, dirs, T, H, t, a_in, a_out, p_drop, seed, _stream()), "sparch_gate_step")
+
+
+class GatedLayerFn(torch.autograd.Function):
+    """LiGRU / GRU baseline layers (anns.py:412-462, 540-595): x (B,T,K) -> dropout(y) (B,T,H*dirs).
+    Launch-per-step this round: per time step the recurrent products run on the exact-split GEMMs and the
+    gate arithmetic in `sparch_gate_step`; projections, normalisation and all weight gradients are whole-
+    sequence GEMMs as for the other layers.  mats = ("c", "z") for LiGRU, ("c", "z", "r") for GRU; the tensor
+    arguments come in groups (W, Wb, norm weight, norm bias, V) per matrix in that order."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        _require_device(x, "input")
+        kind, norm, training, dirs = cfg["kind"], cfg["normalization"], cfg["training"], cfg["dirs"]
+        mats = ("c", "z", "r") if kind == "GRU" else ("c", "z")
+        P = {m: dict(zip(("W", "Wb", "nw", "nb", "V"), params[5 * i:5 * i + 5])) for i, m in enumerate(mats)}
+        x = _f32c(x)
+        B, T, K = x.shape
+        H = P["c"]["W"].shape[0]
+        if H % 4 != 0:
+            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
+        M, Bp, dev = B * T, B * dirs, x.device
+        x2 = x.view(M, K)
+        proj = {}
+        for m in mats:
+            raw, colstat = gemm_nt(x2, P[m]["W"], P[m]["Wb"], colstat=(norm == "batchnorm" and training))
+            z_in, sc, sh, nsaved = _Norm.forward(norm, raw, colstat, P[m]["nw"], P[m]["nb"], cfg["running"][m][0],
+                                                 cfg["running"][m][1], training, dirs)
+            proj[m] = dict(raw=raw, z_in=z_in, sc=sc, sh=sh, nsaved=nsaved)
+        Vgate = torch.cat([P["z"]["V"], P["r"]["V"] if kind == "GRU" else P["c"]["V"]], dim=0).contiguous()  # (2H,H)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        y_state, z_save, c_save = new(Bp, T, H), new(Bp, T, H), new(Bp, T, H)
+        r_save = new(Bp, T, H) if kind == "GRU" else None
+        ry = new(Bp, H) if kind == "GRU" else None
+        y_out = new(B, T, H * dirs)
+        ins = {"Wx": proj["c"]["z_in"], "sc": proj["c"]["sc"], "sh": proj["c"]["sh"],
+               "Wzx": proj["z"]["z_in"], "scz": proj["z"]["sc"], "shz": proj["z"]["sh"]}
+        if kind == "GRU":
+            ins.update(Wrx=proj["r"]["z_in"], scr=proj["r"]["sc"], shr=proj["r"]["sh"])
+        outs = {"y_state": y_state, "z_save": z_save, "r_save": r_save, "c_save": c_save, "ry": ry, "y_out": y_out}
+        p_drop, seed = cfg["p_drop"], cfg["seed"]
+        tok = timer.start(f"gated_fwd[{kind}]")
+        for t in range(T):
+            rec = gemm_nt(y_state[:, t - 1, :], Vgate)[0] if t > 0 else None      # y_{t-1} [Vz;V]^T  (anns.py:457-458)
+            if kind == "LiGRU":
+                _gate_step(0, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
+            else:
+                _gate_step(1, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
+                recc = gemm_nt(ry, P["c"]["V"])[0] if t > 0 else None              # (r y_{t-1}) V^T  (anns.py:591)
+                _gate_step(2, B, dirs, T, H, t, dict(ins, rec=recc), outs, p_drop, seed)
+        timer.stop(tok)
+        ctx.cfg, ctx.shape, ctx.mats = cfg, (B, T, K, H), mats
+        ctx.nsaved = {m: proj[m]["nsaved"] for m in mats}
+        ctx.needs_b = {m: P[m]["Wb"] is not None for m in mats}
+        saved = [x2, y_state, z_save, c_save, r_save, Vgate]
+        for m in mats:
+            saved += [P[m]["W"], P[m]["nw"], P[m]["V"], proj[m]["raw"] if norm in ("batchnorm", "layernorm") else None]
+        ctx.save_for_backward(*saved)
+        return y_out
+
+    @staticmethod
+    def backward(ctx, g_y):
+        cfg, mats = ctx.cfg, ctx.mats
+        kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
+        B, T, K, H = ctx.shape
+        sv = ctx.saved_tensors
+        x2, y_state, z_save, c_save, r_save, Vgate = sv[:6]
+        Pm = {m: dict(zip(("W", "nw", "V", "raw"), sv[6 + 4 * i:10 + 4 * i])) for i, m in enumerate(mats)}
+        M, Bp, dev = B * T, B * dirs, x2.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        d_all = {"z": new(Bp, T, H), "c": new(Bp, T, H)}
+        yprev_all = new(Bp, T, H)
+        ry_all = new(Bp, T, H) if kind == "GRU" else None
+        if kind == "GRU":
+            d_all["r"] = new(Bp, T, H)
+        dgate, dcp = new(Bp, 2 * H), (new(Bp, H) if kind == "GRU" else None)
+        cdir = [new(Bp, H), new(Bp, H)]
+        ins = {"g_out": _f32c(g_y)}
+        outs = {"y_state": y_state, "z_save": z_save, "r_save": r_save, "c_save": c_save, "dgate": dgate, "dcp": dcp,
+                "dz_all": d_all["z"], "dc_all": d_all["c"], "dr_all": d_all.get("r"), "yprev_all": yprev_all,
+                "ry_all": ry_all}
+        p_drop, seed = cfg["p_drop"], cfg["seed"]
+        carry_mv = carry_dir = None
+        tok = timer.start(f"gated_bwd[{kind}]")
+        for t in range(T - 1, -1, -1):
+            o = dict(outs, carry_dir_out=cdir[t & 1])
+            i = dict(ins, carry_mv=carry_mv, carry_dir=carry_dir)
+            if kind == "LiGRU":
+                _gate_step(3, B, dirs, T, H, t, i, o, p_drop, seed)
+            else:
+                _gate_step(4, B, dirs, T, H, t, i, o, p_drop, seed)
+                dry = gemm_nn(dcp, Pm["c"]["V"])                     # gradient of r * y_{t-1}
+                _gate_step(5, B, dirs, T, H, t, {"dry": dry}, o, p_drop, seed)
+            if t > 0:
+                carry_mv = gemm_nn(dgate, Vgate)                     # [dz_pre | d*_pre] [Vz; V*]
+                carry_dir = cdir[t & 1]
+        timer.stop(tok)
+        flat = lambda a: a.view(Bp * T, H)  # noqa: E731
+        dV = {"z": gemm_tn(flat(d_all["z"]), flat(yprev_all))}
+        if kind == "GRU":
+            dV["r"] = gemm_tn(flat(d_all["r"]), flat(yprev_all))
+            dV["c"] = gemm_tn(flat(d_all["c"]), flat(ry_all))
+        else:
+            dV["c"] = gemm_tn(flat(d_all["c"]), flat(yprev_all))
+        grads, dx_raws = {}, []
+        for m in mats:
+            if dirs == 2:  # both directions share the projection rows
+                dy = new(B, T, H)
+                check(lib.sparch_add_halves(M * H, ptr(d_all[m]), ptr(dy), _stream()), "sparch_add_halves")
+            else:
+                dy = d_all[m]
+            dx_raw, dnw, dnb = _Norm.backward(norm, dy.view(M, H), Pm[m]["raw"], Pm[m]["nw"], ctx.nsaved[m],
+                                              cfg["training"])
+            dx_raws.append(dx_raw)
+            grads[m] = (gemm_tn(dx_raw, x2), _colsum(dx_raw) if ctx.needs_b[m] else None, dnw, dnb, dV[m])
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = gemm_nn(torch.cat(dx_raws, dim=1), torch.cat([Pm[m]["W"] for m in mats], dim=0)).view(B, T, K)
+        out = [None, dx]
+        for m in mats:
+            out += list(grads[m])
+        return tuple(out)

@@ -785,7 +785,8 @@ def _ann_from_fixture(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout", "ann_RNN_bn", "ann_RNN_bidir"])
+@pytest.mark.parametrize("name", ["ann_MLP_bn", "ann_MLP_ln_bias_noreadout", "ann_RNN_bn", "ann_RNN_bidir",
+                                  "ann_LiGRU_bn", "ann_GRU_bn"])
 def test_mlp_ann_matches_reference_fixture(name):
     """The MLP baseline + ANN readout on the HIP path against the real reference's outputs, loss, gradients,
     running statistics and eval-mode output (tests/golden/ann_MLP_*.npz).  fp32 tolerance, relative to each
@@ -1065,3 +1066,43 @@ def test_training_learns_class_conditional_synthetic_task(sp, neuron_type):
             n += B
     assert float(loss.detach()) < 0.7 * first, (first, float(loss.detach()))
     assert hits / n > 0.6, hits / n
+
+
+@pytest.mark.parametrize("kind,bidir,norm", [("LiGRU", True, "batchnorm"), ("GRU", True, "layernorm"),
+                                             ("GRU", False, "none")])
+def test_gated_baseline_layers_vs_oracle(kind, bidir, norm):
+    """LiGRU / GRU baseline layers (launch-per-step path) against the CPU oracle (pinned to the reference) on
+    shapes beyond the fixtures: bidirectional, bias, every normalisation; fp32 tolerance 2e-4 of each tensor's
+    largest entry (5e-5 on the output)."""
+    from oracle import ann_oracle as ao
+    from sparch_amd import anns
+
+    B, T, C, H = 10, 19, 36, 64
+    torch.manual_seed(23)
+    layer = getattr(anns, kind + "Layer")(C, H, B, dropout=0.0, normalization=norm, use_bias=True, bidirectional=bidir)
+    with torch.no_grad():
+        for n in ("norm", "normz", "normr"):
+            if hasattr(layer, n):
+                getattr(layer, n).weight.uniform_(0.7, 1.3)
+                getattr(layer, n).bias.uniform_(-0.2, 0.2)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(B, T, C, generator=g)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g)
+    p = {"ann.0." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+         for k, v in layer.state_dict().items() if "num_batches" not in k}
+    xr = x.clone().requires_grad_(True)
+    ref = ao.hidden_layer(kind, xr, p, "ann.0", norm, bidir, training=True, running=None)
+    (ref * gy).sum().backward()
+    layer = layer.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    (y * gy.to(DEV)).sum().backward()
+    assert relmax(y.detach().cpu().numpy(), ref.detach().numpy()) <= 5e-5
+    assert relmax(xd.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-4
+    wmax = float(layer.W.weight.grad.abs().max())
+    for k, v in layer.named_parameters():
+        r = p["ann.0." + k].grad.numpy()
+        if k.endswith(".bias") and k[0] == "W" and norm != "none":  # removed by the normalisation: exactly zero in real arithmetic
+            assert np.abs(v.grad.cpu().numpy() - r).max() <= 1e-4 * wmax, k
+            continue
+        assert relmax(v.grad.cpu().numpy(), r) <= 2e-4, k
