@@ -8,9 +8,19 @@ ranks with no data-path exchange; the only collective is the gradient all-reduce
 15.6 MB fp32 at RadLIF 3x1024.  A layer's backward is ONE autograd node (its reverse
 time loop + GEMMs), so all of a layer's parameter gradients appear together.  We
 bucket per layer: a post-accumulate-grad hook counts a layer's parameters and, when
-the last one lands, flattens the bucket and launches an async all-reduce — which
-then runs on RCCL's stream underneath the next (earlier) layer's reverse time loop.
-`finish()` waits, averages and scatters the buckets back before `optimizer.step()`.
+the last one lands, flattens the bucket.  Two launch policies:
+
+  * overlap (models WITHOUT recurrent layers): the bucket's all-reduce is launched at once, async, and
+    runs on RCCL's stream underneath the next (earlier) layer's backward;
+  * deferred (models with RLIF / RadLIF / RNN layers — the default there): ONE all-reduce of all buckets
+    at the end of backward.  The recurrent cells are persistent kernels whose workgroups wait for each other
+    and need every CU of the GPU (one workgroup per CU, the whole register file): an RCCL kernel that holds
+    a few CUs while it waits for a peer rank keeps such a grid from becoming co-resident, and a peer whose
+    own persistent kernel got the GPU first keeps ITS RCCL kernel from starting — a rank that is slightly
+    ahead would then lose up to a whole recurrent launch (1.5 ms) per bucket.  The deferred collective costs
+    a fixed ~0.1-0.2 ms (15.6 MB over 7 xGMI links) instead.  `SPARCH_DP_OVERLAP=0/1` overrides.
+
+`finish()` waits, averages and hands the gradients to `optimizer.step()`.
 
 BatchNorm statistics stay per-rank (standard DDP semantics).
 Works with any torch.distributed backend: "nccl" (= RCCL) on GPUs, "gloo" in CPU tests.
@@ -20,11 +30,18 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, module, process_group=None, buckets=None):
+    def __init__(self, module, process_group=None, buckets=None, overlap=None):
         """buckets: list of lists of parameters (default: one bucket per child of `module.snn` / `module.ann`,
         or a single bucket for arbitrary modules).  Buckets fire in whatever order backward
-        completes them (readout first, input layer last)."""
+        completes them (readout first, input layer last).  overlap: None = by model (see module docstring)."""
+        import os
+
         self.group = process_group
+        layers_all = getattr(module, "snn", None) or getattr(module, "ann", None) or []
+        if overlap is None:
+            env = os.environ.get("SPARCH_DP_OVERLAP", "")
+            overlap = (env == "1") if env in ("0", "1") else not any(hasattr(lay, "V") for lay in layers_all)
+        self.overlap = bool(overlap)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if buckets is None:
             layers = getattr(module, "snn", None) or getattr(module, "ann", None)  # SNN / ANN layer lists
@@ -57,7 +74,7 @@ class GradAllReducer:
         return hook
 
     def _launch(self, bi):
-        if self.world == 1:
+        if self.world == 1 or not self.overlap:
             return
         grads = [p.grad for p in self.buckets[bi]]
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -68,7 +85,21 @@ class GradAllReducer:
         """Wait for every bucket, turn the sums into means and hand them to the optimizer, re-arm for the
         next step.  The averaged gradients stay in the flat bucket: each `.grad` becomes a view of it (one
         scaling kernel per bucket, no copy back)."""
-        if self.world > 1:
+        if self.world > 1 and not self.overlap:
+            for bi, bucket in enumerate(self.buckets):
+                if self._pending[bi] not in (0, len(bucket)):
+                    raise RuntimeError("GradAllReducer: a bucket received only part of its gradients")
+            ps = [p for bi, bucket in enumerate(self.buckets) if self._pending[bi] == 0 for p in bucket]
+            if ps:
+                flat = torch.cat([p.grad.reshape(-1) for p in ps])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.mul_(1.0 / self.world)
+                off = 0
+                for p in ps:
+                    n = p.numel()
+                    p.grad = flat[off:off + n].view_as(p)
+                    off += n
+        elif self.world > 1:
             inv = 1.0 / self.world
             for bi, bucket in enumerate(self.buckets):
                 if self._work[bi] is None:

@@ -67,14 +67,21 @@ class _Toy(torch.nn.Module):
         return x
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, overlap=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     r, w, _ = dp.init_from_env("gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
     net = _Toy()
-    red = dp.GradAllReducer(net)
+    if overlap is None:
+        red = dp.GradAllReducer(net)
+        assert red.overlap is True  # no recurrent (persistent-kernel) layers -> per-layer overlapped launches
+        net.snn[1].V = torch.nn.Identity()  # a layer with a recurrent matrix switches the default to deferred
+        assert dp.GradAllReducer(net).overlap is False
+        del net.snn[1].V
+    else:
+        red = dp.GradAllReducer(net, overlap=overlap)
     assert len(red.buckets) == 3 and red.bytes_per_step == sum(p.numel() for p in net.parameters()) * 4
     g = torch.Generator().manual_seed(5)
     x_all = torch.randn(8, 6, generator=g)
@@ -91,11 +98,12 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_grad_allreducer_gloo_world2():
+@pytest.mark.parametrize("overlap", [None, False])
+def test_grad_allreducer_gloo_world2(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29600 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + (7 if overlap is False else 0)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get()
