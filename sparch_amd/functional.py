@@ -99,7 +99,11 @@ def check_status(device="cuda"):
     w = status_word(device)
     if int(w[0].item()) != 0:
         w.zero_()
-        raise _capi.SparchHipError("recurrent cell kernel: in-kernel wait timed out (SPARCH_ETIMEOUT)")
+        raise _capi.SparchHipError(
+            "recurrent cell kernel: in-kernel wait timed out (SPARCH_ETIMEOUT).  The persistent kernels need one "
+            "workgroup per CU resident at the same time; if the GPU is shared with another process (or "
+            "partitioned), set SPARCH_REC_STEPS_PER_LAUNCH=1 (one launch per time step, no waiting inside).  "
+            "The results of the affected step are invalid.")
 
 
 def rec_steps_per_launch(T):
