@@ -102,6 +102,14 @@ int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const vo
  * bf16 planes and the six largest cross terms are accumulated in fp32 (the rest measures ~1e-8 of
  * sum|a||b|, below an fp32 sgemm's own rounding): fp32-faithful results at 6/16 of the fp32-MFMA cost.  Same argument meaning as
  * sparch_gemm_nt / _nn / _tn (the tn workspace is sparch_gemm_spike_tn_workspace_bytes).          */
+/* Split-K forms for small M*N with a long K (per-step recurrent products of the gated baselines): the
+ * contraction is cut into slabs in `ws` (sparch_gemm6_splitk_workspace_bytes; 0 = not needed) and reduced in
+ * fixed order.  No bias / statistics epilogue.                                                         */
+size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K);
+int sparch_gemm6_nt_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream);
+int sparch_gemm6_nn_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream);
 int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, float* colstat_ws, void* stream);
 int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,

@@ -42,6 +42,9 @@ PROTOTYPES = {
                                        c_int, P, c_size_t, P]),
     "sparch_gemm_spike_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_float, P, c_int, c_int,
                                      c_int, P, c_size_t, P]),
+    "sparch_gemm6_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sparch_gemm6_nt_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P]),
+    "sparch_gemm6_nn_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P]),
     "sparch_gemm6_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm6_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
     "sparch_gemm6_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),

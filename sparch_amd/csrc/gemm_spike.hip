@@ -791,6 +791,61 @@ extern "C" int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, con
     return launch<false, true, 2, EPI_NONE>(g, 1, (hipStream_t)stream);
 }
 
+// Split-K forms of the dense NT / NN products for SMALL M*N with a long K (the per-step recurrent products of
+// the gated baselines: 256 x 2048 x 1024 is 16 tiles on 256 CUs).  splits = sparch_gemm6_splitk_count(M,N,K)
+// slabs of M*N floats in `ws`, reduced in fixed order; no bias / statistics epilogue.
+namespace {
+int small_splits(int M, int N, int K) {
+    using S = Shape<2, true>;
+    const int tiles = cdiv(M, S::BM) * cdiv(N, S::BN);
+    const int kt = cdiv(K, BK);
+    int s = target_wgs(1) / tiles;
+    if (s > kt / 8) s = kt / 8;      // at least 8 K tiles per workgroup: the pipelined kernel's minimum
+    return s < 1 ? 1 : s;
+}
+template <bool B_KM>
+int gemm6_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+    const int splits = small_splits(M, N, K);
+    SArgs g{};
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    if (splits == 1) {
+        g.C = C; g.ldc = ldc; g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0;
+        return launch<false, B_KM, 2, EPI_NONE>(g, 1, st);
+    }
+    if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float)) return SPARCH_EWORKSPACE;
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    int rc = launch<false, B_KM, 2, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, 0, 0);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+}  // namespace
+
+extern "C" size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = small_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+extern "C" int sparch_gemm6_nt_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
+    return gemm6_splitk<false>(M, N, K, A, lda, B, ldb, C, ldc, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int sparch_gemm6_nn_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
+    return gemm6_splitk<true>(M, N, K, A, lda, B, ldb, C, ldc, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                                int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     SPARCH_ENTER();

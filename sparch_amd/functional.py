@@ -799,6 +799,20 @@ class RNNLayerFn(torch.autograd.Function):
         return None, dx, dW, dWb, dnw, dnb, dV
 
 
+def _gemm_small(A, B, nn):
+    """Per-step recurrent product of the gated baselines: A (M,K) @ B^T (nn=False, B (N,K)) or @ B (nn=True,
+    B (K,N)) with M*N small and K long -> split-K form (fills the GPU instead of 16 workgroups)."""
+    M, K = A.shape
+    N = B.shape[1] if nn else B.shape[0]
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    nbytes = lib.sparch_gemm6_splitk_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+    fn = lib.sparch_gemm6_nn_splitk if nn else lib.sparch_gemm6_nt_splitk
+    check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(ws), nbytes, _stream()),
+          "sparch_gemm6_splitk")
+    return C
+
+
 def _gate_step(mode, B, dirs, T, H, t, ins, outs, p_drop, seed):
     """One launch of sparch_gate_step; ins / outs: dicts slot name -> tensor (missing = NULL)."""
     in_names = ["Wx", "sc", "sh", "Wzx", "scz", "shz", "Wrx", "scr", "shr", "rec", "g_out", "carry_mv", "carry_dir", "dry"]
@@ -850,12 +864,12 @@ class GatedLayerFn(torch.autograd.Function):
         p_drop, seed = cfg["p_drop"], cfg["seed"]
         tok = timer.start(f"gated_fwd[{kind}]")
         for t in range(T):
-            rec = gemm_nt(y_state[:, t - 1, :], Vgate)[0] if t > 0 else None      # y_{t-1} [Vz;V]^T  (anns.py:457-458)
+            rec = _gemm_small(y_state[:, t - 1, :], Vgate, nn=False) if t > 0 else None   # y_{t-1} [Vz;V]^T  (anns.py:457-458)
             if kind == "LiGRU":
                 _gate_step(0, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
             else:
                 _gate_step(1, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
-                recc = gemm_nt(ry, P["c"]["V"])[0] if t > 0 else None              # (r y_{t-1}) V^T  (anns.py:591)
+                recc = _gemm_small(ry, P["c"]["V"], nn=False) if t > 0 else None       # (r y_{t-1}) V^T  (anns.py:591)
                 _gate_step(2, B, dirs, T, H, t, dict(ins, rec=recc), outs, p_drop, seed)
         timer.stop(tok)
         ctx.cfg, ctx.shape, ctx.mats = cfg, (B, T, K, H), mats
@@ -898,10 +912,10 @@ class GatedLayerFn(torch.autograd.Function):
                 _gate_step(3, B, dirs, T, H, t, i, o, p_drop, seed)
             else:
                 _gate_step(4, B, dirs, T, H, t, i, o, p_drop, seed)
-                dry = gemm_nn(dcp, Pm["c"]["V"])                     # gradient of r * y_{t-1}
+                dry = _gemm_small(dcp, Pm["c"]["V"], nn=True)        # gradient of r * y_{t-1}
                 _gate_step(5, B, dirs, T, H, t, {"dry": dry}, o, p_drop, seed)
             if t > 0:
-                carry_mv = gemm_nn(dgate, Vgate)                     # [dz_pre | d*_pre] [Vz; V*]
+                carry_mv = _gemm_small(dgate, Vgate, nn=True)        # [dz_pre | d*_pre] [Vz; V*]
                 carry_dir = cdir[t & 1]
         timer.stop(tok)
         flat = lambda a: a.view(Bp * T, H)  # noqa: E731
