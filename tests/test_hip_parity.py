@@ -1106,3 +1106,49 @@ def test_gated_baseline_layers_vs_oracle(kind, bidir, norm):
             assert np.abs(v.grad.cpu().numpy() - r).max() <= 1e-4 * wmax, k
             continue
         assert relmax(v.grad.cpu().numpy(), r) <= 2e-4, k
+
+
+def test_gemm_shape_sweep_pipelined_and_general_paths():
+    """Shape sweep across the split-GEMM variants (pipelined kernel with shifted edge tiles and a peeled K tail,
+    general bounds-checked kernel, split-K counts that do not divide K, bf16 spike planes, odd leading sizes):
+    every result within 2e-6 * sum|a||b| of the fp64 product."""
+    Fn = _Fn()
+    rng = np.random.default_rng(123)
+    shapes = [(260, 132, 264), (516, 388, 1000), (1028, 260, 4100), (300, 1000, 520), (256, 128, 256),
+              (772, 644, 300), (2052, 140, 772), (264, 520, 8200)]
+    for (M, N, K) in shapes:
+        g = torch.Generator().manual_seed(M + N + K)
+        D1 = torch.randn(M, K, generator=g)
+        D2 = torch.randn(N, K, generator=g)
+        S1 = (torch.rand(M, K, generator=g) < 0.1).float()
+        S16 = S1.to(torch.bfloat16)
+
+        def chk(C, ref, bound, what):
+            err = (C.cpu().double() - ref).abs()
+            assert bool((err <= bound).all()), (what, M, N, K, float((err / bound).max()))
+
+        # NT: spike x dense (fp32 spikes and bf16 plane), dense x dense
+        ref = S1.double() @ D2.double().T
+        bnd = (S1.double() @ D2.abs().double().T) * 2e-6 + 1e-6
+        C_a, _ = Fn.gemm_nt(S1.to(DEV), D2.to(DEV), spike_scale=1.0)
+        C_b, _ = Fn.gemm_nt(S1.to(DEV), D2.to(DEV), spike_scale=1.0, a16=S16.to(DEV))
+        chk(C_a, ref, bnd, "spike_nt")
+        assert torch.equal(C_a, C_b)
+        refd = D1.double() @ D2.double().T
+        bndd = (D1.abs().double() @ D2.abs().double().T) * 2e-6 + 1e-6
+        chk(Fn.gemm_nt(D1.to(DEV), D2.to(DEV))[0], refd, bndd, "dense_nt")
+        # NN: dense (M,K) x dense (K,N)
+        chk(Fn.gemm_nn(D1.to(DEV), D2.T.contiguous().to(DEV)), refd, bndd, "dense_nn")
+        # TN over the long axis: operands (K', M') with K' = M here
+        A_t, B_t = D1[:, :min(K, 520)].contiguous(), S1[:, :min(K, 388)].contiguous()   # (M, m2), (M, n2)
+        ref_t = A_t.double().T @ B_t.double()
+        bnd_t = (A_t.abs().double().T @ B_t.double()) * 2e-6 + 1e-6
+        C_t = Fn.gemm_tn(A_t.to(DEV), B_t.to(DEV), spike_side=1, spike_scale=1.0)
+        chk(C_t, ref_t, bnd_t, "spike_tn side 1")
+        C_t16 = Fn.gemm_tn(A_t.to(DEV), B_t.to(torch.bfloat16).to(DEV), spike_side=1, spike_scale=1.0, spike16=True)
+        assert torch.equal(C_t, C_t16)
+        C_t0 = Fn.gemm_tn(B_t.to(DEV), A_t.to(DEV), spike_side=0, spike_scale=1.0)
+        chk(C_t0, ref_t.T, bnd_t.T, "spike_tn side 0")
+        chk(Fn.gemm_tn(A_t.to(DEV), D1[:, :min(K, 260)].contiguous().to(DEV)),
+            A_t.double().T @ D1[:, :min(K, 260)].double(),
+            (A_t.abs().double().T @ D1[:, :min(K, 260)].abs().double()) * 2e-6 + 1e-6, "dense_tn")
