@@ -93,55 +93,77 @@ class _ANNLayer(nn.Module):
                 norm.running_mean if is_bn else None, norm.running_var if is_bn else None)
 
 
-class MLPLayer(_ANNLayer):
-    """anns.py:149-227: y = dropout(sigmoid(norm(W x)))."""
+class _HiddenANNLayer(_ANNLayer):
+    """Shared construction of the four hidden-layer types.  GATES lists the projection / recurrent-matrix
+    suffixes in the reference's creation order (that order fixes the RNG draws: every W?/V? pair first, then
+    the orthogonal initialisation of the V? matrices — anns.py:196, 279-281, 391-396, 514-522)."""
+    GATES = ("",)
+    RECURRENT = True
+    ACT = nn.Sigmoid
 
     def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
                  use_bias=False, bidirectional=False):
         super().__init__()
-        self.input_size = int(input_size)
-        self.hidden_size = int(hidden_size)
-        self.batch_size = batch_size
-        self.dropout = dropout
-        self.normalization = normalization
-        self.use_bias = use_bias
-        self.act_fct = nn.Sigmoid()
-        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
+        self.input_size, self.hidden_size = int(input_size), int(hidden_size)
+        self.dropout, self.normalization, self.use_bias = dropout, normalization, use_bias
+        if self.RECURRENT:
+            self.bidirectional = bidirectional
+            self.batch_size = batch_size * (1 + bidirectional)
+        else:
+            self.batch_size = batch_size
+        self.act_fct = self.ACT()
+        for g in self.GATES:
+            setattr(self, "W" + g, nn.Linear(self.input_size, self.hidden_size, bias=use_bias))
+            if self.RECURRENT:
+                setattr(self, "V" + g, nn.Linear(self.hidden_size, self.hidden_size, bias=False))
+        if self.RECURRENT:
+            for g in self.GATES:
+                nn.init.orthogonal_(getattr(self, "V" + g).weight)
+        self.normalize = False
+        for g in self.GATES:
+            self.normalize = _make_norm(self, "norm" + g, normalization, self.hidden_size)
         self.drop = nn.Dropout(p=dropout)
+
+    def _cfg(self, x, dirs):
+        p_drop = float(self.dropout) if self.training else 0.0
+        return {"normalization": self.normalization, "training": self.training, "dirs": dirs, "p_drop": p_drop,
+                "seed": self._dropout_seed(x.device) if p_drop > 0 else 0}
+
+
+class MLPLayer(_HiddenANNLayer):
+    """anns.py:149-227: y = dropout(sigmoid(norm(W x)))."""
+    RECURRENT = False
 
     def forward(self, x):
         Fn._require_device(x, "input")
         if self.batch_size != x.shape[0]:
             self.batch_size = x.shape[0]
-        p_drop = float(self.dropout) if self.training else 0.0
         nw, nb, rm, rv = self._norm_args()
-        cfg = {"act": "sigmoid", "normalization": self.normalization, "training": self.training, "p_drop": p_drop,
-               "seed": self._dropout_seed(x.device) if p_drop > 0 else 0, "running_mean": rm, "running_var": rv}
+        cfg = dict(self._cfg(x, 1), act="sigmoid", running_mean=rm, running_var=rv)
         return Fn.MLPLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)
 
 
-class _RecurrentANNLayer(_ANNLayer):
+class _RecurrentANNLayer(_HiddenANNLayer):
     KIND = None
+
+    def _rows(self, x):
+        dirs = 2 if self.bidirectional else 1
+        if self.batch_size != x.shape[0] * dirs:
+            self.batch_size = x.shape[0] * dirs
+        return dirs
 
     def forward(self, x):
         """LiGRU / GRU (anns.py:412-447, 540-579): launch-per-step on the HIP kernels (functional.GatedLayerFn)."""
         Fn._require_device(x, "input")
-        dirs = 2 if self.bidirectional else 1
-        rows = x.shape[0] * dirs
-        if self.batch_size != rows:
-            self.batch_size = rows
-        p_drop = float(self.dropout) if self.training else 0.0
-        mats = ("c", "z", "r") if self.KIND == "GRU" else ("c", "z")
-        suffix = {"c": "", "z": "z", "r": "r"}
+        dirs = self._rows(x)
+        mats = {"": "c", "z": "z", "r": "r"}
         params, running = [], {}
-        for m in mats:
-            W, V = getattr(self, "W" + suffix[m]), getattr(self, "V" + suffix[m])
-            nw, nb, rm, rv = self._norm_args("norm" + suffix[m])
+        for g in self.GATES:
+            W, V = getattr(self, "W" + g), getattr(self, "V" + g)
+            nw, nb, rm, rv = self._norm_args("norm" + g)
             params += [W.weight, W.bias, nw, nb, V.weight]
-            running[m] = (rm, rv)
-        cfg = {"kind": self.KIND, "normalization": self.normalization, "training": self.training, "dirs": dirs,
-               "p_drop": p_drop, "seed": self._dropout_seed(x.device) if p_drop > 0 else 0, "running": running}
+            running[mats[g]] = (rm, rv)
+        cfg = dict(self._cfg(x, dirs), kind=self.KIND, running=running)
         return Fn.GatedLayerFn.apply(cfg, x, *params)
 
 
@@ -151,94 +173,20 @@ class RNNLayer(_RecurrentANNLayer):
 
     def forward(self, x):
         Fn._require_device(x, "input")
-        dirs = 2 if self.bidirectional else 1
-        rows = x.shape[0] * dirs
-        if self.batch_size != rows:
-            self.batch_size = rows
-        p_drop = float(self.dropout) if self.training else 0.0
+        dirs = self._rows(x)
         nw, nb, rm, rv = self._norm_args()
-        cfg = {"act": "sigmoid", "normalization": self.normalization, "training": self.training, "dirs": dirs,
-               "p_drop": p_drop, "seed": self._dropout_seed(x.device) if p_drop > 0 else 0,
-               "running_mean": rm, "running_var": rv}
+        cfg = dict(self._cfg(x, dirs), act="sigmoid", running_mean=rm, running_var=rv)
         return Fn.RNNLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb, self.V.weight)
-
-    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
-                 use_bias=False, bidirectional=False):
-        super().__init__()
-        self.input_size = int(input_size)
-        self.hidden_size = int(hidden_size)
-        self.batch_size = batch_size
-        self.dropout = dropout
-        self.normalization = normalization
-        self.use_bias = use_bias
-        self.bidirectional = bidirectional
-        self.batch_size = self.batch_size * (1 + bidirectional)
-        self.act_fct = nn.Sigmoid()
-        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        nn.init.orthogonal_(self.V.weight)
-        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
-        self.drop = nn.Dropout(p=dropout)
 
 
 class LiGRULayer(_RecurrentANNLayer):
     """anns.py:342-462: z = sigmoid(.), c = relu(.), y = z y + (1-z) c; launch-per-step this round."""
-    KIND = "LiGRU"
-
-    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
-                 use_bias=False, bidirectional=False):
-        super().__init__()
-        self.input_size = int(input_size)
-        self.hidden_size = int(hidden_size)
-        self.batch_size = batch_size
-        self.dropout = dropout
-        self.normalization = normalization
-        self.use_bias = use_bias
-        self.bidirectional = bidirectional
-        self.batch_size = self.batch_size * (1 + bidirectional)
-        self.act_fct = nn.ReLU()
-        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        self.Wz = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.Vz = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        nn.init.orthogonal_(self.V.weight)
-        nn.init.orthogonal_(self.Vz.weight)
-        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
-        if self.normalize:
-            _make_norm(self, "normz", normalization, self.hidden_size)
-        self.drop = nn.Dropout(p=dropout)
+    KIND, GATES, ACT = "LiGRU", ("", "z"), nn.ReLU
 
 
 class GRULayer(_RecurrentANNLayer):
     """anns.py:465-595: z, r = sigmoid(.), c = tanh(W x + V (r y)), y = z y + (1-z) c; launch-per-step this round."""
-    KIND = "GRU"
-
-    def __init__(self, input_size, hidden_size, batch_size, dropout=0.0, normalization="batchnorm",
-                 use_bias=False, bidirectional=False):
-        super().__init__()
-        self.input_size = int(input_size)
-        self.hidden_size = int(hidden_size)
-        self.batch_size = batch_size
-        self.dropout = dropout
-        self.normalization = normalization
-        self.use_bias = use_bias
-        self.bidirectional = bidirectional
-        self.batch_size = self.batch_size * (1 + bidirectional)
-        self.act_fct = nn.Tanh()
-        self.W = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.V = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        self.Wz = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.Vz = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        self.Wr = nn.Linear(self.input_size, self.hidden_size, bias=use_bias)
-        self.Vr = nn.Linear(self.hidden_size, self.hidden_size, bias=False)
-        nn.init.orthogonal_(self.V.weight)
-        nn.init.orthogonal_(self.Vz.weight)
-        nn.init.orthogonal_(self.Vr.weight)
-        self.normalize = _make_norm(self, "norm", normalization, self.hidden_size)
-        if self.normalize:
-            _make_norm(self, "normz", normalization, self.hidden_size)
-            _make_norm(self, "normr", normalization, self.hidden_size)
-        self.drop = nn.Dropout(p=dropout)
+    KIND, GATES, ACT = "GRU", ("", "z", "r"), nn.Tanh
 
 
 class ReadoutLayerANN(_ANNLayer):
