@@ -111,8 +111,7 @@ def cell_backward(kind, g_s, Wx, p, u0, w0, s0, U, W, theta=1.0):
         if recurrent:
             ds = ds + (oma * du_next) @ Vm.T
         x = u_t - theta
-        box = ((x > -0.5) & (x <= 0.5)).astype(f32)
-        du = ds * box + alpha * du_next
+        du = np.where((x <= -0.5) | (x > 0.5), f32(0), ds) + alpha * du_next  # masked assignment, snns.py:33-35
         if adaptive:
             du = du + a * dw_next
             dw = beta * dw_next - oma * du

@@ -40,7 +40,10 @@ class _Boxcar(torch.autograd.Function):
     """Heaviside forward, box-car surrogate backward (snns.py:26-36).
 
     forward:  s = 1[x > 0]                      (strict >, snns.py:29)
-    backward: g_x = g_s * 1[-0.5 < x <= 0.5]    (snns.py:33-35)
+    backward: g_x = g_s with the entries where x <= -0.5 or x > 0.5 SET to zero (snns.py:33-35).
+    Assignment, not multiplication: an infinite / NaN upstream gradient is zeroed outside the box-car, and a
+    NaN x (both comparisons false) lets the gradient through — visible in the long-sequence fixture, where
+    unstable neurons overflow fp32.
     """
 
     @staticmethod
@@ -51,8 +54,10 @@ class _Boxcar(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        keep = (x > -0.5) & (x <= 0.5)
-        return g * keep.to(g.dtype)
+        g_x = g.clone()
+        g_x[x <= -0.5] = 0
+        g_x[x > 0.5] = 0
+        return g_x
 
 
 def spike(x):
@@ -180,12 +185,12 @@ def readout_layer(x, p, prefix, u0, *, normalization="batchnorm", training=True,
 
 def snn_forward(x, p, *, neuron_type, num_layers, init_states, normalization="batchnorm",
                 bidirectional=False, use_readout_layer=True, training=True,
-                theta=1.0, stats=None, drop_masks=None):
+                theta=1.0, stats=None, drop_masks=None, spikes_out=None):
     """SNN.forward (snns.py:157-176): layer loop, firing rates = mean over
     (batch, time) of the concatenated post-dropout hidden outputs (171-174).
     `p` is keyed like the reference state_dict ('snn.{i}.alpha', ...);
     `init_states[i]` is dict(u0, s0[, w0]) for hidden layer i and dict(u0) for
-    the readout."""
+    the readout.  `spikes_out` (a list) receives every hidden layer's output."""
     if x.ndim == 4:  # 160-162
         x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
     elif x.ndim != 3:
@@ -200,6 +205,8 @@ def snn_forward(x, p, *, neuron_type, num_layers, init_states, normalization="ba
             drop_mask=None if drop_masks is None else drop_masks[i],
         )
         spikes.append(x)
+    if spikes_out is not None:
+        spikes_out.extend(spikes)
     rates = torch.cat(spikes, dim=2).mean(dim=(0, 1))  # 174
     if use_readout_layer:
         x = readout_layer(

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void act_kernel(int kind, size_t n4, int H, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = zv[e];
-            if (scale) v = v * sc[e] + sh[e];
+            if (scale) v = bn_affine(v, sc[e], sh[e]);
             const float a = act_f(kind, v);
             const float k = drop ? keep_scale(seed, e0 + e, p_drop, inv_keep) : 1.0f;
             o[e] = BWD ? (g[e] * k) * act_df(kind, a) : a * k;

@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x4 affine(const float* W, const float* sc, const f
     if (sc) {
         const f32x4 s = *reinterpret_cast<const f32x4*>(sc + h), b = *reinterpret_cast<const f32x4*>(sh + h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + b[e];
+        for (int e = 0; e < 4; ++e) v[e] = bn_affine(v[e], s[e], b[e]);
     }
     return v;
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float xn = x[j][e];
-                if (has_norm) xn = xn * sc[e] + sh[e];
+                if (has_norm) xn = bn_affine(xn, sc[e], sh[e]);
                 float drive = xn;
                 if (ADAPT) {
                     w[e] = (be[e] * w[e] + pa[e] * u[e]) + pb[e] * s[e];  // snns.py:438
@@ -202,8 +202,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
                 float ds = gs - al[e] * du_n[e];
                 if (ADAPT) ds = ds + pb[e] * dw_n[e];
                 const float xs = u_t[e] - c.theta;
-                const float box = (xs > -0.5f && xs <= 0.5f) ? 1.0f : 0.0f;  // snns.py:34-35
-                float du = ds * box + al[e] * du_n[e];
+                float du = boxcar_gate(ds, xs) + al[e] * du_n[e];            // snns.py:33-35
                 if (ADAPT) du = du + pa[e] * dw_n[e];
                 dwx[e] = oma[e] * du;
                 const float q = up[j][e] - sp[e];
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
             for (int j = 0; j < RU; ++j) {
                 if (t0 + j >= len) break;
                 float xn = x[j];
-                if (scale) xn = xn * sc + sh;
+                if (scale) xn = bn_affine(xn, sc, sh);
                 u = al * u + oma * xn;                                   // snns.py:822
                 if (act) {
                     us[(t0 + j) * CS + cc] = u;

@@ -33,6 +33,16 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 #define SP_B_LO 0.0f
 #define SP_B_HI 2.0f
 
+// The folded BatchNorm affine, in the arithmetic of torch's CPU kernel (probed bitwise on this image's build:
+// alpha = invstd*weight; beta = fma(-mean, alpha, bias); y = fma(x, alpha, beta)).  The library is built with
+// -ffp-contract=off, so the fused forms are spelled out.
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+
+// Box-car surrogate gate of SpikeFunctionBoxcar.backward (snns.py:33-35): the reference CLEARS the entries
+// where x <= -0.5 or x > 0.5 (assignment, not multiplication), so a non-finite incoming gradient is zeroed
+// outside the box and a NaN x (both comparisons false) passes the gradient through.
+__device__ __forceinline__ float boxcar_gate(float g, float x) { return (x <= -0.5f || x > 0.5f) ? 0.0f : g; }
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
     return fminf(fmaxf(x, lo), hi);
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_ti
     const float invstd = 1.0f / sqrtf(var + eps);
     const float sc = gamma[h] * invstd;
     scale[h] = sc;
-    shift[h] = beta[h] - mean * sc;
+    shift[h] = __builtin_fmaf(-mean, sc, beta[h]);
     if (save_mean) save_mean[h] = mean;
     if (save_invstd) save_invstd[h] = invstd;
 }

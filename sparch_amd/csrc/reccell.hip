@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float xn = xs[e];
-            if (has_norm) xn = xn * sc[e] + sh[e];
+            if (has_norm) xn = bn_affine(xn, sc[e], sh[e]);
             float drive = xn + rec[e];                                      // snns.py:572 / 720
             if (ADAPT) {
                 w[e] = (be[e] * w[e] + pa[e] * u[e]) + pb[e] * s[e];        // snns.py:718
@@ -649,8 +649,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             if (ADAPT) ds = ds + pb[e] * dw_n[e];
             ds = ds + rec[e];
             const float xs = u_t[e] - a.theta;
-            const float box = (xs > -0.5f && xs <= 0.5f) ? 1.0f : 0.0f;       // snns.py:34-35
-            float du = ds * box + al[e] * du_n[e];
+            float du = boxcar_gate(ds, xs) + al[e] * du_n[e];                 // snns.py:33-35
             if (ADAPT) du = du + pa[e] * dw_n[e];
             dwx[e] = valid ? (1.0f - al[e]) * du : 0.0f;
             du_new[e] = du;
@@ -916,7 +915,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
             const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
             if (!BWD) {
                 float xn = c0[e];
-                if (a.scale) xn = xn * sc[e] + sh[e];
+                if (a.scale) xn = bn_affine(xn, sc[e], sh[e]);
                 const float y = ann_act(ACT, xn + rec[e]);                      // anns.py:336
                 val[e] = valid ? y : 0.0f;
                 aux[e] = y * k;                                                 // dropout after the cell (323-324)

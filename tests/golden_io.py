@@ -17,6 +17,16 @@ SNN_CASES = [
     "snn_LIF_noreadout",
 ]
 CELL_KINDS = ["LIF", "adLIF", "RLIF", "RadLIF"]
+# fully dyadic networks (tools/gen_golden.py gen_snn_dyadic): spikes reproducible bit for bit in any summation order
+DYADIC_CASES = ["dyadic_RadLIF_none", "dyadic_RLIF_none_bias", "dyadic_RadLIF_bidir_none", "dyadic_RadLIF_bn"]
+DYADIC_LONG = "dyadic_RadLIF_T1000"
+
+
+def layer_spikes(z, k):
+    """Hidden layer k's spike train of a dyadic fixture (stored bit-packed) as a float32 array."""
+    shape = tuple(int(v) for v in z[f"spikes.{k}.shape"])
+    n = int(np.prod(shape))
+    return np.unpackbits(z[f"spikes.{k}"])[:n].reshape(shape).astype(np.float32)
 
 
 def load(name):

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import snn_oracle as orc
-from tests.golden_io import CELL_KINDS, SNN_CASES, load, snn_case
+from tests.golden_io import CELL_KINDS, DYADIC_CASES, DYADIC_LONG, SNN_CASES, layer_spikes, load, snn_case
 
 pytestmark = pytest.mark.gpu
 
@@ -205,7 +205,7 @@ def _cell_inputs(z, kind):
 
 @pytest.mark.parametrize("spl", [1, None])
 @pytest.mark.parametrize("kind", CELL_KINDS)
-def test_cell_forward_backward_vs_reference_golden(kind, spl):
+def test_cell_forward_backward_vs_reference_golden(kind, spl, record_property):
     Fn = _Fn()
     if spl == 1 and kind in ("LIF", "adLIF"):
         pytest.skip("steps_per_launch only applies to recurrent kinds")
@@ -216,20 +216,28 @@ def test_cell_forward_backward_vs_reference_golden(kind, spl):
     Fn.check_status()
     s_np = s.detach().cpu().numpy()
     mism = float((s_np != z["s"]).mean())
+    record_property("spike_mismatch_fraction", mism)
+    print(f"cell_{kind} spl={spl}: spike mismatch fraction vs the reference fixture = {mism:.3e}")
     if kind in ("LIF", "adLIF"):
         assert mism == 0.0, "non-recurrent cell spikes must be bit-identical to the reference"
     else:
         assert mism <= 2e-3, mism
     (s * dev(z["g_s"])).sum().backward()
     Fn.check_status()
+    # rows whose whole trajectory agrees with the reference: their dWx rows must agree too (a row's dWx
+    # depends on that row's trajectory only); parameter gradients sum over all rows, so they are compared
+    # when every row agrees (the fully dyadic network fixtures pin them for the recurrent kinds otherwise)
+    same = (s_np == z["s"]).reshape(s_np.shape[0], -1).all(1)
+    record_property("rows_agreeing", int(same.sum()))
+    assert same.sum() >= 1
+    assert relmax(Wx.grad.cpu().numpy()[same], z["dWx"][same]) <= 2e-4
     if mism == 0.0:
-        assert relmax(Wx.grad.cpu().numpy(), z["dWx"]) <= 2e-4
         for k in p:
             assert relmax(p[k].grad.cpu().numpy(), z["d" + k]) <= 2e-4, k
-        # clamp gating (raw parameter outside its range -> exactly zero grad)
-        assert p["alpha"].grad[0].item() == 0 and p["alpha"].grad[1].item() == 0
-        if "V" in p:
-            assert float(torch.diag(p["V"].grad).abs().max()) == 0.0
+    # clamp gating (raw parameter outside its range -> exactly zero grad)
+    assert p["alpha"].grad[0].item() == 0 and p["alpha"].grad[1].item() == 0
+    if "V" in p:
+        assert float(torch.diag(p["V"].grad).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("spl", [1, 7, None])
@@ -504,6 +512,82 @@ def test_snn_train_step_vs_reference_golden(sp, name):
         assert np.abs(rates_e.cpu().numpy() - z["rates_eval"]).max() <= 2.5 / (cfg["B"] * T) + 1e-6
     else:
         assert np.abs(rates_e.cpu().numpy() - z["rates_eval"]).mean() <= 0.02
+
+
+def _run_dyadic(sp, name, monkeypatch):
+    """One training step of a dyadic fixture's network on the HIP path, fed the fixture's initial states in
+    the reference's draw order.  Returns (cfg, z, per-layer spikes, out, loss, net)."""
+    Fn = _Fn()
+    cfg, x, y, params, init, z = snn_case(name)
+    net = _build(sp, cfg, params).train()
+    order = []
+    for st in init:
+        order += [st[k] for k in ("u0", "w0", "s0") if k in st]
+    states = iter(order)
+
+    def next_state(rows, cols, device):
+        t = next(states)
+        assert tuple(t.shape) == (rows, cols)
+        return t.to(device)
+
+    from sparch_amd import snns as snn_mod
+    monkeypatch.setattr(snn_mod, "_rand_to", next_state)
+    rec = {}
+    for k, lay in enumerate(list(net.snn)[:-1]):
+        def wrapped(inp, orig=lay.forward_with_rate, k=k):
+            s, r = orig(inp)
+            rec[k] = s.detach()
+            return s, r
+        lay.forward_with_rate = wrapped
+    out, rates = net(x.to(DEV))
+    Fn.check_status()
+    loss = orc.train_step_loss(out, rates, y.to(DEV))
+    loss.backward()
+    Fn.check_status()
+    return cfg, z, rec, out, loss, net
+
+
+@pytest.mark.parametrize("name", DYADIC_CASES)
+def test_snn_dyadic_network_bit_equal_spikes_and_gradients(sp, name, monkeypatch):
+    """Whole RLIF / RadLIF networks against the REFERENCE on fully dyadic weights (tools/gen_golden.py
+    gen_snn_dyadic): every W x, s @ V and s0 @ V sum is exact in any order, so the MFMA path must reproduce
+    the reference's spikes BIT FOR BIT through every layer (guaranteed by construction without
+    normalisation; with batchnorm the last bit of the batch variance is order-dependent, `a` >= 0 keeps
+    the map contracting and equality is observed), and then every parameter gradient — V.weight, layer-0 W,
+    the neuron parameters, norm affine — to 2e-4 of its max-abs."""
+    cfg, z, rec, out, loss, net = _run_dyadic(sp, name, monkeypatch)
+    for k in sorted(rec):
+        ref = layer_spikes(z, k)
+        got = rec[k].cpu().numpy()
+        assert ref.sum() > 0
+        assert np.array_equal(got, ref), (k, float((got != ref).mean()))
+    T = cfg["T"]
+    assert np.abs(out.detach().cpu().numpy() - z["out"]).max() <= 2e-5 * T
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5 * max(1.0, abs(float(z["loss"])))
+    for k, v in net.named_parameters():
+        e = relmax(v.grad.cpu().numpy(), z["grad." + k])
+        assert e <= 2e-4, (k, e)
+        if k.endswith("V.weight"):
+            assert float(torch.diag(v.grad).abs().max()) == 0.0
+
+
+def test_snn_long_sequence_non_finite_gradient_mask_matches_reference(sp, monkeypatch):
+    """T = 1000 (BASELINE configs[4] length) on a dyadic RadLIF net: neurons whose subthreshold (u, w) map is
+    unstable overflow fp32 in the reference itself and leave some of ITS alpha / beta / a gradients
+    non-finite.  The fixture holds the reference's gradients; the HIP path must leave exactly the same
+    entries non-finite, parameter by parameter, and agree on the finite ones."""
+    cfg, z, rec, out, loss, net = _run_dyadic(sp, DYADIC_LONG, monkeypatch)
+    for k in sorted(rec):
+        assert np.array_equal(rec[k].cpu().numpy(), layer_spikes(z, k)), k
+    n_bad = 0
+    for k, v in net.named_parameters():
+        g, g_ref = v.grad.cpu().numpy(), z["grad." + k]
+        ok = np.isfinite(g_ref)
+        assert np.array_equal(np.isfinite(g), ok), (k, int((~np.isfinite(g)).sum()), int((~ok).sum()))
+        n_bad += int((~ok).sum())
+        if ok.any():
+            assert relmax(g[ok], g_ref[ok]) <= 2e-4, k
+    assert n_bad > 0
 
 
 def test_eval_mode_batchnorm_gradients_vs_oracle(sp):
@@ -999,9 +1083,10 @@ def test_full_size_cfg_bidirectional_long_sequence(sp):
     # The reference's own subthreshold (u, w) map is unstable for a < ~0 (eigenvalue up to 1.4 per step, see
     # DESIGN.md §2): over 1000 steps the membrane state of such neurons overflows in fp32 — in the reference's
     # arithmetic as in ours — and their alpha / beta / a gradients (du * (inf - inf)) are NaN.  Everything
-    # that does not multiply those states stays finite.  (Checked against the real reference on the CPU at
-    # T=1000, H=64: 34-38 % of its alpha / beta / a gradients are non-finite, b / W / V / norm all finite —
-    # the same pattern and fraction as here.)
+    # that does not multiply those states stays finite.  WHICH entries are non-finite is pinned against the
+    # reference at T=1000, H=64 by test_snn_long_sequence_non_finite_gradient_mask_matches_reference; at this
+    # size no reference run exists (trajectories are not reproducible with real-valued V), so here only the
+    # parameters whose gradients never touch those states are required to be finite.
     for k, v in net.named_parameters():
         assert v.grad is not None, k
         if k.split(".")[-1] not in ("alpha", "beta", "a"):

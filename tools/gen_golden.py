@@ -178,6 +178,96 @@ def gen_snn(name, neuron_type, layer_sizes, B, T, C, *, normalization="batchnorm
          **{"param." + k: v for k, v in params0.items()}, **states, **grads, **stats1)
 
 
+# ----------------------------------------------------------------------------
+# 2b. whole SNN on a fully DYADIC network: every matrix product is exact in fp32
+# ----------------------------------------------------------------------------
+class quantized_rand:
+    """While active, torch.rand returns its usual draw rounded down to a multiple of 2^-4.  The reference's
+    code is untouched: it still calls torch.rand for u0 / w0 / s0 (snns.py:286-287 ...), it just receives
+    initial states on a coarse grid, so that the t = 0 product s0 @ V is exact like every later one."""
+
+    def __enter__(self):
+        self.orig = torch.rand
+        orig = self.orig
+        torch.rand = lambda *a, **k: torch.floor(orig(*a, **k) * 16.0) / 16.0
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self.orig
+
+
+def gen_snn_dyadic(name, neuron_type, layer_sizes, B, T, C, *, normalization="none", use_bias=False,
+                   bidirectional=False, p_in=0.3, w_gain=4.0, seed=2024, nonneg_a=False, grads_finite=True):
+    """W, V (and biases) on a 2^-6 grid, 0/1 input, initial states on a 2^-4 grid: every W x, s @ V and
+    s0 @ V partial sum is a small multiple of 2^-10 and therefore exact in fp32 in ANY summation order, so
+    an implementation with a different GEMM k-order (MFMA vs the CPU sgemm) must still reproduce the
+    reference's spikes bit for bit through all layers (normalization='none'); with batchnorm the statistics
+    are order-dependent in the last bit, gamma is a power of two, `a` >= 0 keeps the subthreshold map
+    contracting, and bit-equality is expected but not guaranteed by construction.
+    Stored besides the usual outputs: every hidden layer's spike train (bit-packed)."""
+    torch.manual_seed(seed)
+    net = ref.SNN(input_shape=(B, None, C), layer_sizes=layer_sizes, neuron_type=neuron_type, dropout=0.0,
+                  normalization=normalization, use_bias=use_bias, bidirectional=bidirectional,
+                  use_readout_layer=True)
+    q = lambda t, gain=1.0: torch.round(t * gain * 64.0) / 64.0  # noqa: E731
+    with torch.no_grad():
+        for lay in net.snn:
+            lay.W.weight.copy_(q(lay.W.weight, w_gain))
+            if use_bias:
+                lay.W.bias.copy_(q(lay.W.bias, w_gain))
+            if hasattr(lay, "V"):
+                lay.V.weight.copy_(q(lay.V.weight))
+            if nonneg_a and hasattr(lay, "a"):
+                lay.a.abs_().mul_(0.01)
+            if hasattr(lay, "norm"):
+                lay.norm.weight.copy_(2.0 ** torch.randint(-1, 2, lay.norm.weight.shape).float())
+                lay.norm.bias.copy_(q(torch.rand(lay.norm.bias.shape) * 1.0 + 1.0))
+    gen = torch.Generator().manual_seed(4321)
+    x = (torch.rand(B, T, C, generator=gen) < p_in).float()
+    n_cls = layer_sizes[-1]
+    y = torch.randint(0, n_cls, (B,), generator=gen)
+    params0 = {k: npy(v) for k, v in net.state_dict().items()}
+
+    spikes = {}
+    hooks = [lay.register_forward_hook(lambda m, i, o, k=k: spikes.__setitem__(k, o.detach()))
+             for k, lay in enumerate(list(net.snn)[:-1])]
+    net.train()
+    fwd_seed = seed + 77
+    with quantized_rand():
+        torch.manual_seed(fwd_seed)
+        out, rates = net(x)
+        loss = F.cross_entropy(out, y)
+        loss.backward()
+        torch.manual_seed(fwd_seed)
+        Bp = B * (2 if bidirectional else 1)
+        states = {}
+        for i in range(len(layer_sizes) - 1):
+            for k, v in draw_states(Bp, layer_sizes[i], ADAPTIVE[neuron_type]).items():
+                states[f"init.{i}.{k}"] = npy(v)
+        states[f"init.{len(layer_sizes) - 1}.u0"] = npy(torch.rand(B, n_cls))
+    for h in hooks:
+        h.remove()
+    grads = {"grad." + k: npy(v.grad) for k, v in net.named_parameters()}
+    n_bad = sum(int((~np.isfinite(g)).sum()) for g in grads.values())
+    if grads_finite:
+        assert n_bad == 0, f"{name}: {n_bad} non-finite gradient entries"
+    stats1 = {"after." + k: npy(v) for k, v in net.state_dict().items() if "running" in k}
+    packed = {}
+    for k, s in spikes.items():
+        s_np = npy(s)
+        assert set(np.unique(s_np)) <= {0.0, 1.0}
+        packed[f"spikes.{k}"] = np.packbits(s_np.astype(np.uint8), axis=None)
+        packed[f"spikes.{k}.shape"] = np.array(s_np.shape)
+        print(f"  layer {k}: firing rate {s_np.mean():.4f}")
+    print(f"  non-finite gradient entries: {n_bad}")
+    save(name, x=npy(x).astype(np.uint8), y=npy(y), out=npy(out), rates=npy(rates), loss=npy(loss),
+         cfg=np.array(json.dumps(dict(
+             neuron_type=neuron_type, layer_sizes=layer_sizes, B=B, T=T, C=C, normalization=normalization,
+             use_bias=use_bias, bidirectional=bidirectional, use_readout_layer=True, use_regularizers=False,
+             fwd_seed=fwd_seed, build_seed=seed, dyadic=True))),
+         **{"param." + k: v for k, v in params0.items()}, **states, **grads, **stats1, **packed)
+
+
 def gen_ann(name, ann_type, layer_sizes, B, T, C, *, normalization="batchnorm", use_bias=False,
             bidirectional=False, use_readout_layer=True, seed=4242):
     """Non-spiking baselines (anns.py): MLP / RNN / LiGRU / GRU + ReadoutLayerANN.  No random initial state
@@ -255,6 +345,16 @@ def main():
     gen_snn("snn_LIF_noreadout", "LIF", [32, 24], 4, 20, 40,
             use_readout_layer=False, use_regularizers=False, p_in=0.2)
     gen_reference_checkpoint()
+    # fully dyadic networks: spikes reproducible bit for bit by any summation order (see gen_snn_dyadic)
+    gen_snn_dyadic("dyadic_RadLIF_none", "RadLIF", [64, 64, 20], 8, 40, 64)
+    gen_snn_dyadic("dyadic_RLIF_none_bias", "RLIF", [64, 32, 20], 6, 32, 48, use_bias=True, seed=2025, w_gain=10.0,
+                   p_in=0.4)
+    gen_snn_dyadic("dyadic_RadLIF_bidir_none", "RadLIF", [32, 32, 20], 4, 24, 40, bidirectional=True, seed=2026)
+    gen_snn_dyadic("dyadic_RadLIF_bn", "RadLIF", [64, 64, 20], 8, 32, 64, normalization="batchnorm",
+                   nonneg_a=True, w_gain=1.0, seed=2027)
+    # long sequence (BASELINE configs[4] is T = 1000): neurons whose (u, w) map is unstable overflow fp32 and
+    # the reference's own alpha / beta / a gradients become non-finite; the fixture pins WHICH entries
+    gen_snn_dyadic("dyadic_RadLIF_T1000", "RadLIF", [64, 64, 20], 4, 1000, 32, seed=2028, grads_finite=False)
     # f-4: non-spiking baselines
     gen_ann("ann_MLP_bn", "MLP", [48, 48, 20], 6, 30, 40)
     gen_ann("ann_MLP_ln_bias_noreadout", "MLP", [32, 24], 4, 20, 40, normalization="layernorm", use_bias=True,
