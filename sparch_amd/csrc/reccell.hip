@@ -28,14 +28,21 @@
 //                  per (step, row): never reused inside a call;
 //       backward — the fp32 32x32 tile of dWx_t, stored in MFMA-FRAGMENT ORDER (16-byte piece
 //                  (ks*2+q)*64 + h*32 + row) into a depth-4 ring with 16-byte sc1 (write-through)
-//                  stores, drained (vmcnt(0)) + workgroup barrier, then one sc1 tag store
-//                  (tag = T - t); consumers poll the tag and read the tile with 16-byte sc1 loads
-//                  (G16 form R1) — every wave-load is one contiguous 1 KiB (8 whole lines), where
-//                  reading the natural (B,T,H) layout touched 32 lines for 32 B each — and split
-//                  it into three exact bf16 planes in registers (truncation split: v_perm for the
-//                  high halves, AND + SUB for the residuals).  Lock-step makes ring depth 2
-//                  sufficient: a workgroup writes step t-1 only after it has read every peer's
-//                  step t, which they produced after reading every step t+1 tile;
+//                  stores, and NOTHING ELSE: no drain, no tag.  The data is the flag here too: every
+//                  ring slot holds a SENTINEL bit pattern (a signalling NaN, which no fp32 arithmetic
+//                  result can be: hardware quiets NaNs) until its 16-byte piece lands, and consumers
+//                  simply load the tile (16-byte sc1 loads, every wave-load one contiguous 1 KiB) and
+//                  re-load the pieces that still read as the sentinel (first and last word checked;
+//                  16-byte sc1 stores are observed untorn on gfx950).  A producer puts the sentinel
+//                  back into its slot of step t+2 while it works on step t: by then it has seen every
+//                  peer's step t+1 tile, which they produced after consuming every step t+2 tile, and
+//                  its next vmcnt(0) (the tile loads of step t-1) retires that store before it
+//                  publishes step t-1 — the store a consumer must see before it can ask for step t-2,
+//                  the slot's next content.  Against the first version (tile stores, drain, barrier,
+//                  tag store; consumers poll the tag, barrier, then load): one store->load visibility
+//                  hop instead of two per step and two workgroup barriers fewer.  Consumers split the
+//                  fp32 values into three exact bf16 planes in registers (truncation split: v_perm for
+//                  the high halves, AND + SUB for the residuals);
 //   * block -> tile mapping keeps a batch tile's workgroups at equal blockIdx % n_row_tiles,
 //     i.e. on one XCD under round-robin dispatch.  That is a speed choice only: every
 //     hand-off is agent-scope and placement-independent.  Every spin is bounded by a
@@ -73,7 +80,14 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #ifndef REC_ST_AUX
 #define REC_ST_AUX 16 /* sc1 */
 #endif
+#ifndef REC_AHEAD
+#define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
+#endif
 constexpr u64 TIMEOUT_TICKS = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
+// "not written yet" pattern of the backward / dense hand-off ring: a SIGNALLING NaN.  Arithmetic results are
+// never signalling (the hardware quiets every NaN it produces or propagates, IEEE mode), so no tile value
+// can equal it.
+constexpr unsigned SENTINEL = 0x7FA5A5A5u;
 
 struct RecArgs {
     int B, dirs, T, H, Bp;
@@ -90,7 +104,7 @@ struct RecArgs {
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; uint16_t* s_prev16; float* dparam_ws;
     // hand-off
-    u64* chan; unsigned* flags; char* ring; unsigned* status;
+    u64* chan; char* ring; unsigned* status;
 };
 
 // Diagnostic build only (-DSPARCH_REC_PROF, never shipped): per-workgroup sums of s_memtime
@@ -118,6 +132,19 @@ __device__ u64 g_rec_prof[2][512][8];
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Workgroup barrier for LDS hand-offs inside the time loops.  __syncthreads() also carries workgroup-scope
+// release / acquire fences on GLOBAL memory, i.e. an `s_waitcnt vmcnt(0)`: every wave would wait for the
+// acknowledgement of its write-through hand-off stores (~2 k cycles) and of its bulk output stores at every
+// barrier.  The loops only exchange LDS data across these barriers (cross-workgroup data goes through sc1
+// accesses that need no fence), so: LDS operations retired, then the bare barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// `s_waitcnt vmcnt(0)` as the builtin (the compiler's wait-count pass sees it and clears its scoreboard, unlike
+// an asm statement).  Placed where every outstanding vector-memory operation is long complete anyway, it keeps
+// hipcc from inserting its own conservative vmcnt(0) at a later join — e.g. behind the hand-off stores, where
+// it would wait ~2 k cycles for their write-through acknowledgements.
+__device__ __forceinline__ void vm_settled() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot) {
     __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -153,6 +180,74 @@ __device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4*
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 vb[kk][ks][p] = vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane];
+    }
+}
+
+
+// Load this wave's k-groups of a row tile's fp32 hand-off tiles (fragment order) from ring slot `base`,
+// re-loading every 16-byte piece that still holds the sentinel until all have landed (bounded spin).
+// lane (row li, k-half hh) of k16-step ks needs k = 16*ks + 8*hh + 4q + 0..3 of producer tile kg:
+// piece (ks*2+q)*64 + lane of that tile -> each wave-load is 1 KiB contiguous.
+__device__ __forceinline__ bool piece_missing(const u32x4& v) { return v[0] == SENTINEL || v[3] == SENTINEL; }
+
+// issue the four 1 KiB wave-loads of ONE k-group
+template <int NW>
+__device__ __forceinline__ void issue_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg,
+                                           int n_ct) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // padding k-groups (beyond H) read past the end of the buffer resource: the hardware returns
+            // zeros for out-of-range buffer loads — no branch, and zeros are never "missing"
+            const unsigned off = kg < n_ct ? base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024)
+                                           : 0xFFFFFF00u;
+            g[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
+        }
+}
+
+// the four pieces of ONE k-group: wait for them (the others stay in flight), re-load what still reads as the
+// sentinel until it has landed (bounded spin).  Fast path: four compares and one wave-uniform branch.
+__device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base,
+                                            int* abort_slot) {
+    unsigned miss = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) miss |= piece_missing(g[ks][q]) ? (1u << (ks * 2 + q)) : 0u;
+    if (__any(miss != 0)) {
+        // slow path.  Re-loads go to temporaries and are waited for right here (builtin wait: the compiler's
+        // scoreboard stays exact), then merged by select: the pending loads of the later k-groups are not
+        // touched, so the fast path keeps its precise vmcnt(N) waits after the join.
+        const u64 t_start = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            u32x4 tmp[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    tmp[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * 2 + q) * 1024),
+                                                                      0, REC_LD_AUX);
+            vm_settled();
+            unsigned still = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned bit = 1u << (ks * 2 + q);
+                    const bool m = (miss & bit) != 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[ks][q][e] = m ? tmp[ks][q][e] : g[ks][q][e];
+                    if (m && piece_missing(tmp[ks][q])) still |= bit;
+                }
+            miss = still;
+            if (!__any(miss != 0)) break;
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                *(volatile int*)abort_slot = 1;  // the status word is raised at the kernel's exit
+                break;
+            }
+        }
     }
 }
 
@@ -324,7 +419,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             }
             PROF_STAMP(1);  // expand + MFMA + LDS write
         }
-        __syncthreads();
+        lds_barrier();
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
         if (t > 0) {
@@ -412,13 +507,18 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 // other's stalls.  The pointwise reverse step and the stores stay on the first 256 threads.
 template <bool ADAPT, int KGW, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
+    // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
+    // waves, which reach the second (publish) barrier only when done with them -> one buffer
+    __shared__ __attribute__((aligned(16))) float red[NW][RT * RED_LD];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
     // per-thread neuron constants (alpha, beta, a, b, rate gradient of the thread's 4 columns): kept in LDS
     // and re-read each step — the 8-wave kernel's 256-register budget has no room to hold them
     __shared__ __attribute__((aligned(16))) f32x4 pconst[5][256];
+    // running parameter-gradient partial sums (alpha, beta, a, b) of the thread's 4 columns: touched once per
+    // step, off the critical path -> LDS, so that the hot loop's registers do not spill
+    __shared__ __attribute__((aligned(16))) f32x4 pacc[4][256];
     __shared__ int abort_flag[2];
 
     const int tid = threadIdx.x;
@@ -449,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
     }
 
-    float du_n[4], dw_n[4], u_t[4], acc_al[4], acc_be[4], acc_a[4], acc_b[4];
+    float du_n[4], dw_n[4], u_t[4];
     if (pw) {
         f32x4 c_al, c_be, c_a, c_b, c_gr;
 #pragma unroll
@@ -465,20 +565,22 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         du_n[e] = dw_n[e] = 0.f;
-        acc_al[e] = acc_be[e] = acc_a[e] = acc_b[e] = 0.f;
     }
     const size_t plane = (size_t)a.Bp * H;
     float* ws = a.dparam_ws + (size_t)bpc * H + colc;
-    if (a.t_end < T) {  // resume a chunked pass: carried state + partial sums
-        f32x4 v;
-        v = ld4(ws); acc_al[0] = v.x; acc_al[1] = v.y; acc_al[2] = v.z; acc_al[3] = v.w;
-        v = ld4(ws + 4 * plane); du_n[0] = v.x; du_n[1] = v.y; du_n[2] = v.z; du_n[3] = v.w;
-        if (ADAPT) {
-            v = ld4(ws + plane); acc_be[0] = v.x; acc_be[1] = v.y; acc_be[2] = v.z; acc_be[3] = v.w;
-            v = ld4(ws + 2 * plane); acc_a[0] = v.x; acc_a[1] = v.y; acc_a[2] = v.z; acc_a[3] = v.w;
-            v = ld4(ws + 3 * plane); acc_b[0] = v.x; acc_b[1] = v.y; acc_b[2] = v.z; acc_b[3] = v.w;
-            v = ld4(ws + 5 * plane); dw_n[0] = v.x; dw_n[1] = v.y; dw_n[2] = v.z; dw_n[3] = v.w;
+    if (pw) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v_al = z4, v_be = z4, v_a = z4, v_b = z4;
+        if (a.t_end < T) {  // resume a chunked pass: carried state + partial sums
+            f32x4 v;
+            v_al = ld4(ws);
+            v = ld4(ws + 4 * plane); du_n[0] = v.x; du_n[1] = v.y; du_n[2] = v.z; du_n[3] = v.w;
+            if (ADAPT) {
+                v_be = ld4(ws + plane); v_a = ld4(ws + 2 * plane); v_b = ld4(ws + 3 * plane);
+                v = ld4(ws + 5 * plane); dw_n[0] = v.x; dw_n[1] = v.y; dw_n[2] = v.z; dw_n[3] = v.w;
+            }
         }
+        pacc[0][tid] = v_al; pacc[1][tid] = v_be; pacc[2][tid] = v_a; pacc[3][tid] = v_b;
     }
     {
         const f32x4 v = ld4(a.u_save + ((size_t)bpc * T + (a.t_end - 1)) * H + colc);
@@ -520,57 +622,31 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
 
         if (t + 1 < T) {
-            // ---- wait for the dWx_{t+1} tiles of this wave's producers, then read them (sc1): all
-            //      loads in flight before the first MFMA
+            // ---- the dWx_{t+1} tiles of this wave's producers: load, re-load what has not landed yet
             const unsigned slot = (unsigned)((t + 1) % RING);
-            const unsigned want = (unsigned)(T - (t + 1));
-            const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
-            // ONE wave polls, one 128-byte load per sweep (lane i reads the tag of producer column tile i);
-            // the others wait at the barrier.  (Every wave polling its own producers' tags put 8 x 4
-            // agent-scope loads per workgroup per sweep on the one memory channel that holds a row tile's
-            // tag line, and the producers' tag stores queued behind them.)
-            if (wave == 0) {
-                const u64 t_start = __builtin_amdgcn_s_memrealtime();
-                const unsigned m = (lane < a.n_ct) ? 0xFFFFFFFFu : 0u;
-                for (unsigned spins = 0;; ++spins) {
-                    const unsigned tg = __hip_atomic_load(fl + min(lane, a.n_ct - 1), __ATOMIC_RELAXED, REC_LD_SCOPE);
-                    if (__all(((tg ^ want) & m) == 0)) break;
-                    if ((spins & 63u) == 63u &&
-                        __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                        raise_timeout(a.status, &abort_flag[par]);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            __syncthreads();
-            if (*(volatile int*)&abort_flag[par]) break;
-            PROF_STAMP(0);  // flag wait
-            // lane (row li, k-half hh) of k16-step ks needs k = 16*ks + 8*hh + 4q + 0..3 of producer tile kg:
-            // piece (ks*2+q)*64 + lane of that tile -> each wave-load is 1 KiB contiguous
             const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
+            // The CU's fill rate from L2 (~70 GB/s: 128 KiB of tiles per step take ~3.7 k cycles) holds a wave
+            // in the ISSUE of its loads once the memory pipeline is full, so the issue is spread out: two
+            // k-groups ahead of the one being multiplied, the rest of the loads interleaved with the MFMAs
+            // (the partner wave on the SIMD computes while this one is stuck issuing).
+            constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;
             u32x4 raw[KGW][2][2];
 #pragma unroll
-            for (int kk = 0; kk < KGW; ++kk) {
-                const int kg = wave + NW * kk;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        if (kg < a.n_ct) {
-                            const unsigned off = base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024);
-                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
-                        } else {
-                            raw[kk][ks][q] = u32x4{0u, 0u, 0u, 0u};
-                        }
-                    }
-            }
+            for (int kk = 0; kk < AHEAD; ++kk) issue_tile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
+            PROF_STAMP(0);  // first tile load issue
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
-                {   // branch-free on purpose (padding k-groups hold zeros): one basic block for the scheduler
+                // k-group by k-group: the MFMAs of one run while the loads of the next are still in flight
+                // (scheduling barriers: hipcc otherwise hoists the next group's check, and its wait, into this
+                // group's MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                settle_tile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * TILE_BYTES, &abort_flag[par]);
+                if (kk + AHEAD < KGW) issue_tile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
+                __builtin_amdgcn_sched_barrier(0);
+                {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         // exact truncation split of the 8 fp32 values into three bf16 fragments
@@ -604,24 +680,25 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     }
                 }
             }
-            float* rd = red[par][wave];
+            float* rd = red[wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 rd[row * RED_LD + li] = acc[i];
             }
-            PROF_STAMP(1);  // tile loads + split + MFMA + LDS write
+            PROF_STAMP(1);  // per k-group: wait, split, MFMA; LDS write
         }
-        __syncthreads();
+        lds_barrier();
+        vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[par]) break;
         if (t + 1 < T) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
-                float sum = red[par][0][o];
+                float sum = red[0][o];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) sum = sum + red[par][w][o];
+                for (int w = 1; w < NW; ++w) sum = sum + red[w][o];
                 rec[e] = sum;
             }
         }
@@ -635,6 +712,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             for (int e = 0; e < 4; ++e) sp[e] = (upv[e] - a.theta) > 0.0f ? 1.0f : 0.0f;
         } else {
             const f32x4 v = ld4(a.s0 + (size_t)bpc * H + colc);
+            vm_settled();  // last step only; keeps this load's wait out of the code behind the publish stores
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
         }
         f32x4 dwx, spv;
@@ -657,24 +735,29 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             spv[e] = (t > 0) ? sp[e] : 0.0f;  // binary rows only: the s0 term of dV is added by the host
         }
         // ---- publish dWx_t first: this thread's 4 values are one 16-byte piece of the tile in fragment
-        //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1);
-        //      write-through, drain, barrier, tag
-        if (pw && t > 0) {
+        //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1), one
+        //      write-through store; then the sentinel goes back into the slot of step t+2 (see header)
+        if (pw) {
             const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
-            const unsigned off = (unsigned)(t % RING) * slot_bytes + rt_off + (unsigned)ct * TILE_BYTES + piece;
-            u32x4 rawv;
+            const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
+            if (t > 0) {
+                u32x4 rawv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, REC_ST_AUX);
+                for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
+                __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, (unsigned)(t % RING) * slot_bytes + tile_off, 0,
+                                                       REC_ST_AUX);
+            }
+            if (t + 2 < T) {
+                const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+                __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (unsigned)((t + 2) % RING) * slot_bytes + tile_off,
+                                                       0, REC_ST_AUX);
+            }
         }
         PROF_STAMP(3);  // pointwise + tile store issue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PROF_STAMP(4);  // drain
-        __syncthreads();
-        if (tid == 0 && t > 0) {
-            gu32* f = (gu32*)a.flags + ((size_t)(t % RING) * a.n_rt_total + rt) * a.n_ct + ct;
-            __hip_atomic_store(f, (unsigned)(T - t), __ATOMIC_RELAXED, REC_ST_SCOPE);
-        }
+#ifndef REC_NO_PUBLISH_BARRIER
+        lds_barrier();  // the non-pointwise waves start polling only once this workgroup's own tile is on its way
+#endif
+        PROF_STAMP(4);  // publish barrier
         // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
         if (valid) {
             st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
@@ -683,36 +766,47 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             h.y = (spv[2] != 0.f ? 0x3F80u : 0u) | (spv[3] != 0.f ? 0x3F800000u : 0u);
             *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt) * H + col) = h;
         }
+        if (pw) {
+            f32x4 v_al = pacc[0][pt], v_be, v_a, v_b;
+            if (ADAPT) { v_be = pacc[1][pt]; v_a = pacc[2][pt]; v_b = pacc[3][pt]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = upv[e] - sp[e];
+                v_al[e] += du_new[e] * (q - u_t[e]);  // x 1/(1-alpha) once, at the end
+                if (ADAPT) {
+                    v_be[e] += dw_new[e] * wpv[e];
+                    v_a[e] += dw_new[e] * upv[e];
+                    v_b[e] += dw_new[e] * sp[e];
+                }
+            }
+            pacc[0][pt] = v_al;
+            if (ADAPT) { pacc[1][pt] = v_be; pacc[2][pt] = v_a; pacc[3][pt] = v_b; }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float q = upv[e] - sp[e];
-            acc_al[e] += du_new[e] * (q - u_t[e]);  // x 1/(1-alpha) once, at the end
-            if (ADAPT) {
-                acc_be[e] += dw_new[e] * wpv[e];
-                acc_a[e] += dw_new[e] * upv[e];
-                acc_b[e] += dw_new[e] * sp[e];
-                dw_n[e] = dw_new[e];
-            }
+            if (ADAPT) dw_n[e] = dw_new[e];
             du_n[e] = du_new[e];
             u_t[e] = upv[e];
         }
-        PROF_STAMP(5);  // barrier + tag + fp32 stores + partial sums
+        PROF_STAMP(5);  // fp32 stores + partial sums
     }
     PROF_FLUSH(1)
+    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (valid) {
-        f32x4 v;
+        f32x4 v = pacc[0][tid];
         if (a.t_begin == 0) {  // last chunk of the pass: d u_t / d alpha = (q - u_t) / (1 - alpha)
             const f32x4 al = pconst[0][tid & 255];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc_al[e] = acc_al[e] / (1.0f - al[e]);
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f - al[e]);
         }
-        v.x = acc_al[0]; v.y = acc_al[1]; v.z = acc_al[2]; v.w = acc_al[3]; st4(ws, v);
+        st4(ws, v);
         v.x = du_n[0]; v.y = du_n[1]; v.z = du_n[2]; v.w = du_n[3]; st4(ws + 4 * plane, v);
         if (ADAPT) {
-            v.x = acc_be[0]; v.y = acc_be[1]; v.z = acc_be[2]; v.w = acc_be[3]; st4(ws + plane, v);
-            v.x = acc_a[0]; v.y = acc_a[1]; v.z = acc_a[2]; v.w = acc_a[3]; st4(ws + 2 * plane, v);
-            v.x = acc_b[0]; v.y = acc_b[1]; v.z = acc_b[2]; v.w = acc_b[3]; st4(ws + 3 * plane, v);
+            st4(ws + plane, pacc[1][tid]);
+            st4(ws + 2 * plane, pacc[2][tid]);
+            st4(ws + 3 * plane, pacc[3][tid]);
             v.x = dw_n[0]; v.y = dw_n[1]; v.z = dw_n[2]; v.w = dw_n[3]; st4(ws + 5 * plane, v);
         }
     }
@@ -726,7 +820,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 // PREVIOUS step's dense fp32 row tile (handed over through the tagged ring, split exactly into three bf16
 // planes by the consumer) with its resident slice of V (six cross terms), then applies a pointwise rule and
 // publishes its own 32 x 32 tile.  `s` counts steps in processing order (forward: t = s, backward:
-// t = T-1-s); the tile of step s goes to ring slot s % RING with tag s + 1.
+// t = T-1-s); the tile of step s goes to ring slot s % RING (sentinel protocol of the spiking backward).
 struct AnnArgs {
     int B, dirs, T, H, Bp;
     int n_ct, nkg, n_rt_total;
@@ -738,7 +832,7 @@ struct AnnArgs {
     float* y_state; float* y_out;                  // forward outputs
     const float* g_out; const float* y_in;         // backward inputs (y_in = the forward's y_state)
     float* dpre; float* y_prev;                    // backward outputs
-    unsigned* flags; char* ring; unsigned* status;
+    char* ring; unsigned* status;
 };
 
 __device__ __forceinline__ float ann_act(int kind, float v) {
@@ -820,45 +914,20 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
 
         if (s > 0) {
             const unsigned slot = (unsigned)((s - 1) % RING);
-            const unsigned want = (unsigned)s;
-            const gu32* fl = (const gu32*)a.flags + ((size_t)slot * a.n_rt_total + rt) * a.n_ct;
-            if (wave == 0) {  // one polling wave, one 128-byte load per sweep (see rec_bwd_kernel)
-                const u64 t_start = __builtin_amdgcn_s_memrealtime();
-                const unsigned m = (lane < a.n_ct) ? 0xFFFFFFFFu : 0u;
-                for (unsigned spins = 0;; ++spins) {
-                    const unsigned tg = __hip_atomic_load(fl + min(lane, a.n_ct - 1), __ATOMIC_RELAXED, REC_LD_SCOPE);
-                    if (__all(((tg ^ want) & m) == 0)) break;
-                    if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                        raise_timeout(a.status, &abort_flag[par]);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            __syncthreads();
-            if (*(volatile int*)&abort_flag[par]) break;
             const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
+            constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;  // see rec_bwd_kernel
             u32x4 raw[KGW][2][2];
 #pragma unroll
-            for (int kk = 0; kk < KGW; ++kk) {
-                const int kg = wave + NW * kk;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        if (kg < a.n_ct) {
-                            const unsigned off = base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024);
-                            raw[kk][ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
-                        } else {
-                            raw[kk][ks][q] = u32x4{0u, 0u, 0u, 0u};
-                        }
-                    }
-            }
+            for (int kk = 0; kk < AHEAD; ++kk) issue_tile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
+                __builtin_amdgcn_sched_barrier(0);
+                settle_tile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * TILE_BYTES, &abort_flag[par]);
+                if (kk + AHEAD < KGW) issue_tile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     u32x4 p1, p2, p3;  // exact truncation split of the 8 fp32 values
@@ -892,7 +961,8 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
                 rd[row * RED_LD + li] = acc[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
+        vm_settled();
         if (*(volatile int*)&abort_flag[par]) break;
         if (s > 0) {
 #pragma unroll
@@ -925,21 +995,25 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
                 aux[e] = c2[e];
             }
         }
-        // ---- publish this step's tile (fragment order), write-through; drain; barrier; tag
-        if (pw && s + 1 < T) {
+        // ---- publish this step's tile (fragment order, write-through); put the sentinel back into the slot
+        //      of step s-2 (every peer has consumed it: they have all published step s-1 since)
+        if (pw) {
             const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
-            const unsigned off = (unsigned)(s % RING) * slot_bytes + rt_off + (unsigned)ct * TILE_BYTES + piece;
-            u32x4 rawv;
+            const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
+            if (s + 1 < T) {
+                u32x4 rawv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(val[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, off, 0, REC_ST_AUX);
+                for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(val[e]);
+                __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, (unsigned)(s % RING) * slot_bytes + tile_off, 0,
+                                                       REC_ST_AUX);
+            }
+            if (s >= 2) {
+                const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+                __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (unsigned)((s - 2) % RING) * slot_bytes + tile_off,
+                                                       0, REC_ST_AUX);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0 && s + 1 < T) {
-            gu32* f = (gu32*)a.flags + ((size_t)(s % RING) * a.n_rt_total + rt) * a.n_ct + ct;
-            __hip_atomic_store(f, (unsigned)(s + 1), __ATOMIC_RELAXED, REC_ST_SCOPE);
-        }
+        lds_barrier();
         // ---- off the critical path: outputs
         if (valid) {
             if (!BWD) {
@@ -951,6 +1025,8 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
             }
         }
     }
+    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------ V prepack
@@ -999,10 +1075,6 @@ int pick_kgw(int H) {
 size_t fwd_chan_bytes(int Bp, int T, int H) {
     return (size_t)T * cdiv(Bp, RT) * cdiv(H, CT) * 32 * sizeof(u64);
 }
-size_t bwd_flag_bytes(int Bp, int H) {
-    const size_t b = (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * sizeof(unsigned);
-    return (b + 255) / 256 * 256;
-}
 size_t bwd_ring_bytes(int Bp, int H) {
     return (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * TILE_BYTES;
 }
@@ -1036,11 +1108,10 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     if (!a.chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
     if (!BWD) {
         if (hipMemsetAsync(a.chan, 0, fwd_chan_bytes(a.Bp, a.T, a.H), st) != hipSuccess) return SPARCH_ELAUNCH;
-    } else {
-        const size_t fb = bwd_flag_bytes(a.Bp, a.H);
-        if (hipMemsetAsync(a.chan, 0, fb, st) != hipSuccess) return SPARCH_ELAUNCH;
-        a.flags = reinterpret_cast<unsigned*>(a.chan);
-        a.ring = reinterpret_cast<char*>(a.chan) + fb;
+    } else {  // every ring piece reads "not written yet" until its producer's store lands
+        if (hipMemsetD32Async((hipDeviceptr_t)a.chan, (int)SENTINEL, bwd_ring_bytes(a.Bp, a.H) / 4, st) != hipSuccess)
+            return SPARCH_ELAUNCH;
+        a.ring = reinterpret_cast<char*>(a.chan);
     }
 
     int L = steps_per_launch;
@@ -1100,10 +1171,9 @@ int run_ann(int act, AnnArgs& a, void* chan, size_t chan_bytes, int steps_per_la
     a.nkg = 4 * kgw;
     a.n_rt_total = cdiv(a.Bp, RT);
     if (!chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
-    const size_t fb = bwd_flag_bytes(a.Bp, a.H);
-    if (hipMemsetAsync(chan, 0, fb, st) != hipSuccess) return SPARCH_ELAUNCH;
-    a.flags = reinterpret_cast<unsigned*>(chan);
-    a.ring = reinterpret_cast<char*>(chan) + fb;
+    if (hipMemsetD32Async((hipDeviceptr_t)chan, (int)SENTINEL, bwd_ring_bytes(a.Bp, a.H) / 4, st) != hipSuccess)
+        return SPARCH_ELAUNCH;
+    a.ring = reinterpret_cast<char*>(chan);
     int L = steps_per_launch;
     if (L < 1) L = 1;
     if (L > a.T) L = a.T;
@@ -1179,8 +1249,8 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
 
 extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
-    // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: tags + fp32 tile ring
-    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_flag_bytes(Bp, H) + bwd_ring_bytes(Bp, H);
+    // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: fp32 tile ring
+    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_ring_bytes(Bp, H);
     return f > b ? f : b;
 }
 

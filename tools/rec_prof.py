@@ -45,7 +45,7 @@ torch.cuda.synchronize()
 lib.sparch_rec_prof_read(buf.ctypes.data, 1)
 print(f"fwd+bwd wall {e0.elapsed_time(e1):.3f} ms, firing rate {float(s.mean()):.4f}")
 names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-"],
-         ["flag wait", "loads+mfma+lds", "barrier", "pointwise+stores", "drain vmcnt", "barrier+flag"]]
+         ["first load issue", "wait+split+mfma+lds", "barrier", "pointwise+publish", "publish barrier", "stores+partial sums"]]
 for w, label in enumerate(("forward", "backward")):
     a = buf[w, :256, :6].astype(np.float64) / T
     print(f"{label}: cycles per step (mean over workgroups | min | max)")
