@@ -224,6 +224,8 @@ size_t sparch_vpack_bytes(int H);
 /* transpose: bit 0 = pack V^T, bit 1 = keep the diagonal (dense cells of the ANN baselines) */
 int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked,
                  void* stream);
+/* vmasked (H,H) = V with its diagonal zeroed (snns.py:566/712), any H */
+int sparch_vmask(int H, const float* V, float* vmasked, void* stream);
 size_t sparch_rec_chan_bytes(int Bp, int T, int H);
 int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
                         const float* scale, const float* shift, const float* alpha,
@@ -245,6 +247,28 @@ int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_
                         uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
                         void* chan, size_t chan_bytes, uint32_t* status,
                         int steps_per_launch, void* stream);
+/* ONE time step t of the same cells with the recurrent product supplied by the caller — the path for hidden
+ * sizes whose V slice does not fit the persistent kernels' register-resident layout (H > 1024; the reference
+ * accepts any nb_hiddens, snns.py:608-661): any grid size, nothing waits inside a launch.
+ *   forward : rec (Bp,H) = s_{t-1} @ V  (t = 0: s0 @ V, V with its diagonal zeroed); the step's raw
+ *             (pre-dropout) spikes also go to s_step16 (Bp,H) bf16 0/1, the operand of the next product;
+ *             membrane / adaptation state is carried through u_save / w_save (row t-1 is read)
+ *   backward: steps run t = T-1 ... 0; rec (Bp,H) = dWx_{t+1} @ V^T (ignored at t = T-1); the step's dWx
+ *             also goes to dwx_step (Bp,H); du / dw carries and the parameter partial sums live in
+ *             dparam_ws (6 planes of Bp*H) between calls.                                          */
+int sparch_rec_cell_step_fwd(int kind, int B, int dirs, int T, int H, int t, const float* Wx,
+                             const float* scale, const float* shift, const float* alpha,
+                             const float* beta, const float* a, const float* b, const float* rec,
+                             const float* u0, const float* w0, const float* s0, float theta,
+                             float p_drop, uint64_t seed, float* s_out, uint16_t* s16_out,
+                             float* u_save, float* w_save, uint32_t* spike_count,
+                             uint16_t* s_step16, void* stream);
+int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H, int t, const float* g_out,
+                             const float* g_rate, const float* u_save, const float* w_save,
+                             const float* alpha, const float* beta, const float* a, const float* b,
+                             const float* rec, const float* u0, const float* w0, const float* s0,
+                             float theta, float p_drop, uint64_t seed, float* dWx,
+                             uint16_t* s_prev16, float* dparam_ws, float* dwx_step, void* stream);
 
 /* Finish per-row partials: out[j][h] = sum_r ws[j][r][h], zeroed where the raw parameter
  * lies outside [lo_j, hi_j] (torch.clamp's gradient gate).  n_params <= 4; raw[j]/lim may
@@ -330,6 +354,16 @@ int sparch_ann_rec_bwd(int act, int B, int dirs, int T, int H, const float* g_ou
                        const float* vpack, float p_drop, uint64_t seed, float* dpre, float* y_prev,
                        void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
                        void* stream);
+/* ONE step of the same cell with the recurrent product supplied by the caller (hidden sizes > 1024, see
+ * sparch_rec_cell_step_fwd).  `s` counts steps in processing order (forward t = s, backward t = T-1-s);
+ * rec (Bp,H) = y_{t-1} V^T (forward) / dpre_{t+1} V (backward), ignored at s = 0; the step's y / dpre also
+ * goes to the contiguous (Bp,H) buffer y_step / dpre_step.                                          */
+int sparch_ann_rec_step_fwd(int act, int B, int dirs, int T, int H, int s, const float* Wx,
+                            const float* scale, const float* shift, const float* rec, float p_drop,
+                            uint64_t seed, float* y_out, float* y_state, float* y_step, void* stream);
+int sparch_ann_rec_step_bwd(int act, int B, int dirs, int T, int H, int s, const float* g_out,
+                            const float* y_state, const float* rec, float p_drop, uint64_t seed,
+                            float* dpre, float* y_prev, float* dpre_step, void* stream);
 
 /* Gate arithmetic of ONE time step of the gated baselines (LiGRULayer._ligru_cell anns.py:449-462,
  * GRULayer._gru_cell anns.py:581-595); the recurrent products between the phases are GEMM calls.  This

@@ -244,14 +244,21 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
 // crossbar per time step: 137 us forward / 194 us backward for 256 x 250 x 35.)
 constexpr int RT = 128;  // time steps per chunk
 constexpr int RU = 8;    // global loads in flight per lane in the recurrence phases
+// More than 64 classes: NW waves per batch row (lane -> thread index, wave barrier -> workgroup barrier).
+template <int NW>
+__device__ __forceinline__ void ro_barrier() {
+    if (NW == 1) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
 
-__global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, const float* __restrict__ Wx,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void readout_fwd_kernel(int B, int T, int C, const float* __restrict__ Wx,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ alpha,
                                                          const float* __restrict__ u0, float* __restrict__ out,
                                                          float* __restrict__ u_save) {
-    __shared__ float us[RT * 65];
+    __shared__ float us[RT * (64 * NW + 1)];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int CS = C | 1;
@@ -280,9 +287,9 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
         // lane = time: softmax over classes, in place
-        for (int tl = lane; tl < len; tl += 64) {
+        for (int tl = lane; tl < len; tl += 64 * NW) {
             float* row = us + tl * CS;
             float m = row[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
             }
             for (int c = 0; c < C; ++c) row[c] = row[c] / den;
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
         // lane = class: out += softmax(u_t) in time order                 // snns.py:823
         if (act) {
             for (int t0 = 0; t0 < len; t0 += RU) {  // reads first (independent), then the ordered adds
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
                     if (t0 + j < len) acc = acc + pv[j];
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
     }
     if (act) out[(size_t)b * C + cc] = acc;
 }
@@ -315,13 +322,14 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int B, int T, int C, co
 //   e_t = p_t * (g - <p_t, g>)            (lane = time; independent over t)
 //   du_t = alpha du_{t+1} + e_t,  dWx_t = (1-alpha) du_t,  dalpha += du_t (u_{t-1} - u_t) / (1-alpha)
 //                                          (lane = class; reverse time)
-__global__ __launch_bounds__(64) void readout_bwd_kernel(int B, int T, int C, const float* __restrict__ g_out,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int C, const float* __restrict__ g_out,
                                                          const float* __restrict__ u_save,
                                                          const float* __restrict__ alpha,
                                                          const float* __restrict__ u0, float* __restrict__ dWx,
                                                          float* __restrict__ dalpha_ws) {
-    __shared__ float us[RT * 65];
-    __shared__ float gs[64];
+    __shared__ float us[RT * (64 * NW + 1)];
+    __shared__ float gs[64 * NW];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int CS = C | 1;
@@ -343,9 +351,9 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int B, int T, int C, co
             for (int j = 0; j < RU; ++j)
                 if (t0 + j < len && act) us[(t0 + j) * CS + cc] = x[j];
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
         // lane = time: e_t in place
-        for (int tl = lane; tl < len; tl += 64) {
+        for (int tl = lane; tl < len; tl += 64 * NW) {
             float* row = us + tl * CS;
             float m = row[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int B, int T, int C, co
             }
             for (int c = 0; c < C; ++c) row[c] = row[c] * (gs[c] - dot);
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
         // lane = class: reverse recurrence; u_{t-1} - u_t re-read from u_save (coalesced, prefetched)
         for (int t0 = len - 1; t0 >= 0; t0 -= RU) {
             float uc[RU + 1];  // uc[j] = u_{t0-j}, uc[RU] = u_{t0-RU}
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int B, int T, int C, co
                 acc += du * (uc[j + 1] - uc[j]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ro_barrier<NW>();
     }
     if (act) dalpha_ws[(size_t)b * C + cc] = acc / oma;
 }
@@ -472,9 +480,13 @@ extern "C" int sparch_readout_fwd(int B, int T, int C, const float* Wx, const fl
                                   const float* shift, const float* alpha, const float* u0, float* out,
                                   float* u_save, void* stream) {
     SPARCH_ENTER();
-    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !Wx || !alpha || !u0 || !out) return SPARCH_EINVAL;
+    if (B <= 0 || T <= 0 || C <= 0 || C > 256 || !Wx || !alpha || !u0 || !out) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
-    hipLaunchKernelGGL(readout_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
+    if (C > 128)     hipLaunchKernelGGL(readout_fwd_kernel<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
+                                        alpha, u0, out, u_save);
+    else if (C > 64) hipLaunchKernelGGL(readout_fwd_kernel<2>, dim3(B), dim3(128), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
+                                        alpha, u0, out, u_save);
+    else hipLaunchKernelGGL(readout_fwd_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
                        alpha, u0, out, u_save);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -486,9 +498,13 @@ extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const
                                   void* stream) {
     SPARCH_ENTER();
     (void)Wx; (void)scale; (void)shift;  // dalpha uses u_{t-1}-x_t = (u_{t-1}-u_t)/(1-alpha): no re-read of Wx
-    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
+    if (B <= 0 || T <= 0 || C <= 0 || C > 256 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
         return SPARCH_EINVAL;
-    hipLaunchKernelGGL(readout_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
+    if (C > 128)     hipLaunchKernelGGL(readout_bwd_kernel<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
+                                        alpha, u0, dWx, dalpha_ws);
+    else if (C > 64) hipLaunchKernelGGL(readout_bwd_kernel<2>, dim3(B), dim3(128), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
+                                        alpha, u0, dWx, dalpha_ws);
+    else hipLaunchKernelGGL(readout_bwd_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
                        alpha, u0, dWx, dalpha_ws);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;

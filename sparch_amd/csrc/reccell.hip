@@ -97,6 +97,10 @@ struct RecArgs {
     const float* Wx; const float* scale; const float* shift;
     const float* alpha; const float* beta; const float* a; const float* b;
     const u32x4* vpack; const float* rec0;
+    // step variants (EXT): the recurrent product of the ONE step [t_begin, t_begin+1) is supplied by the caller
+    // in rec0 (Bp,H); the step's raw spikes (forward, bf16 0/1) / dWx (backward, fp32) also go to a contiguous
+    // (Bp,H) buffer, the operand of the caller's next product
+    uint16_t* s_step16; float* dwx_step;
     const float* u0; const float* w0; const float* s0;
     float theta, p_drop, inv_keep; uint64_t seed;
     float* s_out; uint16_t* s16_out; float* u_save; float* w_save; uint32_t* spike_count;
@@ -255,7 +259,7 @@ __device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rs
 // NW waves per workgroup, each taking the k-groups kg = wave + NW*kk of the contraction (partial tiles
 // summed through LDS); NW = 8 puts two waves on each SIMD so that one's LUT reads / poll latency sit
 // under the other's MFMAs.  Pointwise update, publish and stores stay on the first 256 threads.
-template <bool ADAPT, int KGW, int NW>
+template <bool ADAPT, int KGW, int NW, bool EXT = false>
 __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     const int d = bpc / a.B, b = bpc - d * a.B;
 
     u32x4 vb[KGW][2][3];
-    load_vslice<KGW, NW>(vb, a.vpack, ct, a.nkg, wave, lane);
+    if (!EXT) load_vslice<KGW, NW>(vb, a.vpack, ct, a.nkg, wave, lane);
     if (pw) {
         u32x4 e;
 #pragma unroll
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         const f32x4 xv = x_next;
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
 
-        if (t == 0) {
+        if (t == 0 || EXT) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
             if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         lds_barrier();
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
-        if (t > 0) {
+        if (t > 0 && !EXT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
@@ -460,7 +464,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
         word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x141, 0xF, 0xF, true);  // row_half_mirror
-        if (pw && cq == 0 && t + 1 < T) {
+        if (EXT) {
+            if (valid) {  // the step's raw (pre-dropout) spikes: operand of the caller's s_t @ V product
+                u32x2 h;
+                h.x = (s[0] != 0.f ? 0x3F80u : 0u) | (s[1] != 0.f ? 0x3F800000u : 0u);
+                h.y = (s[2] != 0.f ? 0x3F80u : 0u) | (s[3] != 0.f ? 0x3F800000u : 0u);
+                *reinterpret_cast<u32x2*>(a.s_step16 + (size_t)bp * H + col) = h;
+            }
+        } else if (pw && cq == 0 && t + 1 < T) {
             gu64* slot = (gu64*)a.chan + (((size_t)t * a.n_rt_total + rt) * a.n_ct + ct) * 32 + r;
             __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 // per step a SIMD has 112 MFMAs, ~770 VALU instructions of splitting and 32 tile loads to issue, and with
 // a single wave those queue behind each other (and behind the first load's latency); two waves fill each
 // other's stalls.  The pointwise reverse step and the stores stay on the first 256 threads.
-template <bool ADAPT, int KGW, int NW>
+template <bool ADAPT, int KGW, int NW, bool EXT = false>
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
     // waves, which reach the second (publish) barrier only when done with them -> one buffer
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 
     u32x4 vb[KGW][2][2];
 #pragma unroll
-    for (int kk = 0; kk < KGW; ++kk) {
+    for (int kk = 0; kk < (EXT ? 0 : KGW); ++kk) {
         const int kg = wave + NW * kk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         const int par = t & 1;
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
 
-        if (t + 1 < T) {
+        if (t + 1 < T && !EXT) {
             // ---- the dWx_{t+1} tiles of this wave's producers: load, re-load what has not landed yet
             const unsigned slot = (unsigned)((t + 1) % RING);
             const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
@@ -692,7 +703,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[par]) break;
-        if (t + 1 < T) {
+        if (t + 1 < T && EXT) {
+            const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
+            rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
+        } else if (t + 1 < T) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
@@ -737,7 +751,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // ---- publish dWx_t first: this thread's 4 values are one 16-byte piece of the tile in fragment
         //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1), one
         //      write-through store; then the sentinel goes back into the slot of step t+2 (see header)
-        if (pw) {
+        if (EXT) {
+            if (valid) st4(a.dwx_step + (size_t)bp * H + col, dwx);  // operand of the caller's dWx_t @ V^T product
+        } else if (pw) {
             const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
             const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
             if (t > 0) {
@@ -833,6 +849,9 @@ struct AnnArgs {
     const float* g_out; const float* y_in;         // backward inputs (y_in = the forward's y_state)
     float* dpre; float* y_prev;                    // backward outputs
     char* ring; unsigned* status;
+    // step variant (EXT): this ONE step's recurrent product comes from the caller (Bp,H); the step's y / dpre
+    // also goes to a contiguous (Bp,H) buffer, the operand of the caller's next product
+    const float* rec_ext; float* step_out;
 };
 
 __device__ __forceinline__ float ann_act(int kind, float v) {
@@ -846,7 +865,7 @@ __device__ __forceinline__ float ann_dact(int kind, float a) {  // through the a
     return 1.0f - a * a;
 }
 
-template <int ACT, bool BWD, int KGW, int NW>
+template <int ACT, bool BWD, int KGW, int NW, bool EXT = false>
 __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
@@ -869,7 +888,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
 
     u32x4 vb[KGW][2][2];
 #pragma unroll
-    for (int kk = 0; kk < KGW; ++kk) {
+    for (int kk = 0; kk < (EXT ? 0 : KGW); ++kk) {
         const int kg = wave + NW * kk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -912,7 +931,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         const int par = s & 1;
         if (pw && s + 1 < a.s_end) load_step(s + 1, n0, n1, n2);
 
-        if (s > 0) {
+        if (s > 0 && !EXT) {
             const unsigned slot = (unsigned)((s - 1) % RING);
             const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
             constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;  // see rec_bwd_kernel
@@ -964,7 +983,10 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         lds_barrier();
         vm_settled();
         if (*(volatile int*)&abort_flag[par]) break;
-        if (s > 0) {
+        if (s > 0 && EXT) {
+            const f32x4 v = ld4(a.rec_ext + (size_t)bpc * H + colc);
+            rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
+        } else if (s > 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int o = r * RED_LD + cq * 4 + e;
@@ -997,7 +1019,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         }
         // ---- publish this step's tile (fragment order, write-through); put the sentinel back into the slot
         //      of step s-2 (every peer has consumed it: they have all published step s-1 since)
-        if (pw) {
+        if (EXT) {
+            if (valid) st4(a.step_out + (size_t)bp * H + col, val);
+        } else if (pw) {
             const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
             const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
             if (s + 1 < T) {
@@ -1247,6 +1271,15 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
     return SPARCH_OK;
 }
 
+extern "C" int sparch_vmask(int H, const float* V, float* vmasked, void* stream) {
+    SPARCH_ENTER();
+    if (H <= 0 || !V || !vmasked) return SPARCH_EINVAL;
+    const size_t n = (size_t)H * H;
+    hipLaunchKernelGGL(vmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, V, vmasked);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
 extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
     // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: fp32 tile ring
@@ -1346,4 +1379,126 @@ extern "C" int sparch_ann_rec_bwd(int act, int B, int dirs, int T, int H, const 
     a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
     a.dpre = dpre; a.y_prev = y_prev; a.status = status;
     return run_ann<true>(act, a, chan, chan_bytes, steps_per_launch, (hipStream_t)stream);
+}
+
+// ---- one time step with the recurrent product supplied by the caller: the path for hidden sizes whose V slice
+//      does not fit the register-resident layout (H > 1024), any grid size, no inter-workgroup hand-off
+extern "C" int sparch_rec_cell_step_fwd(int kind, int B, int dirs, int T, int H, int t, const float* Wx,
+                                        const float* scale, const float* shift, const float* alpha,
+                                        const float* beta, const float* a, const float* b, const float* rec,
+                                        const float* u0, const float* w0, const float* s0, float theta,
+                                        float p_drop, uint64_t seed, float* s_out, uint16_t* s16_out,
+                                        float* u_save, float* w_save, uint32_t* spike_count,
+                                        uint16_t* s_step16, void* stream) {
+    SPARCH_ENTER();
+    if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
+    const bool adapt = kind == SPARCH_KIND_RADLIF;
+    if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2) || t < 0 || t >= T) return SPARCH_EINVAL;
+    if (!Wx || !alpha || !rec || !u0 || !s0 || !s_out || !u_save || !s_step16) return SPARCH_EINVAL;
+    if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({Wx, rec, u0, w0, s0, s_out, s16_out, u_save, w_save, s_step16})) return SPARCH_EALIGN;
+    RecArgs r{};
+    r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
+    r.n_ct = cdiv(H, CT); r.nkg = 4; r.n_rt_total = cdiv(r.Bp, RT); r.rt_base = 0; r.n_rt_launch = r.n_rt_total;
+    r.t_begin = t; r.t_end = t + 1;
+    r.Wx = Wx; r.scale = scale; r.shift = shift;
+    r.alpha = alpha; r.beta = beta; r.a = a; r.b = b; r.rec0 = rec; r.u0 = u0; r.w0 = w0; r.s0 = s0;
+    r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
+    r.s_out = s_out; r.s16_out = s16_out; r.u_save = u_save; r.w_save = w_save; r.spike_count = spike_count;
+    r.s_step16 = s_step16;
+    const unsigned grid = (unsigned)(r.n_ct * r.n_rt_total);
+    hipStream_t st = (hipStream_t)stream;
+    if (adapt) hipLaunchKernelGGL((rec_fwd_kernel<true, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);
+    else       hipLaunchKernelGGL((rec_fwd_kernel<false, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H, int t, const float* g_out,
+                                        const float* g_rate, const float* u_save, const float* w_save,
+                                        const float* alpha, const float* beta, const float* a, const float* b,
+                                        const float* rec, const float* u0, const float* w0, const float* s0,
+                                        float theta, float p_drop, uint64_t seed, float* dWx,
+                                        uint16_t* s_prev16, float* dparam_ws, float* dwx_step, void* stream) {
+    SPARCH_ENTER();
+    if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
+    const bool adapt = kind == SPARCH_KIND_RADLIF;
+    if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2) || t < 0 || t >= T) return SPARCH_EINVAL;
+    if (!g_out || !u_save || !alpha || !u0 || !s0 || !dWx || !s_prev16 || !dparam_ws || !dwx_step) return SPARCH_EINVAL;
+    if (t + 1 < T && !rec) return SPARCH_EINVAL;
+    if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({g_out, u_save, w_save, rec, u0, w0, s0, dWx, s_prev16, dparam_ws, dwx_step})) return SPARCH_EALIGN;
+    RecArgs r{};
+    r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
+    r.n_ct = cdiv(H, CT); r.nkg = 4; r.n_rt_total = cdiv(r.Bp, RT); r.rt_base = 0; r.n_rt_launch = r.n_rt_total;
+    r.t_begin = t; r.t_end = t + 1;
+    r.alpha = alpha; r.beta = beta; r.a = a; r.b = b; r.rec0 = rec; r.u0 = u0; r.w0 = w0; r.s0 = s0;
+    r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
+    r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
+    r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
+    r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws; r.dwx_step = dwx_step;
+    const unsigned grid = (unsigned)(r.n_ct * r.n_rt_total);
+    hipStream_t st = (hipStream_t)stream;
+    if (adapt) hipLaunchKernelGGL((rec_bwd_kernel<true, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);
+    else       hipLaunchKernelGGL((rec_bwd_kernel<false, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+namespace {
+template <bool BWD>
+int launch_ann_step(int act, const AnnArgs& a, hipStream_t st) {
+    const unsigned grid = (unsigned)(a.n_ct * a.n_rt_total);
+    switch (act) {
+        case SPARCH_ACT_SIGMOID:
+            hipLaunchKernelGGL((ann_rec_kernel<SPARCH_ACT_SIGMOID, BWD, 1, 4, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case SPARCH_ACT_RELU:
+            hipLaunchKernelGGL((ann_rec_kernel<SPARCH_ACT_RELU, BWD, 1, 4, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case SPARCH_ACT_TANH:
+            hipLaunchKernelGGL((ann_rec_kernel<SPARCH_ACT_TANH, BWD, 1, 4, true>), dim3(grid), dim3(256), 0, st, a); break;
+        default: return SPARCH_EINVAL;
+    }
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+}  // namespace
+
+/* `s` counts steps in processing order (forward: t = s; backward: t = T-1-s); rec = y_{t-1} V^T (forward) /
+ * dpre_{t+1} V (backward), ignored at s = 0. */
+extern "C" int sparch_ann_rec_step_fwd(int act, int B, int dirs, int T, int H, int s, const float* Wx,
+                                       const float* scale, const float* shift, const float* rec, float p_drop,
+                                       uint64_t seed, float* y_out, float* y_state, float* y_step, void* stream) {
+    SPARCH_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4 != 0 || (dirs != 1 && dirs != 2) || s < 0 || s >= T) return SPARCH_EINVAL;
+    if (!Wx || !y_out || !y_state || !y_step || (s > 0 && !rec)) return SPARCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({Wx, scale, shift, rec, y_out, y_state, y_step})) return SPARCH_EALIGN;
+    AnnArgs a{};
+    a.B = B; a.dirs = dirs; a.T = T; a.H = H; a.Bp = B * dirs;
+    a.n_ct = cdiv(H, CT); a.nkg = 4; a.n_rt_total = cdiv(a.Bp, RT); a.rt_base = 0; a.n_rt_launch = a.n_rt_total;
+    a.s_begin = s; a.s_end = s + 1;
+    a.Wx = Wx; a.scale = scale; a.shift = shift; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    a.y_state = y_state; a.y_out = y_out; a.rec_ext = rec; a.step_out = y_step;
+    return launch_ann_step<false>(act, a, (hipStream_t)stream);
+}
+
+extern "C" int sparch_ann_rec_step_bwd(int act, int B, int dirs, int T, int H, int s, const float* g_out,
+                                       const float* y_state, const float* rec, float p_drop, uint64_t seed,
+                                       float* dpre, float* y_prev, float* dpre_step, void* stream) {
+    SPARCH_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || H % 4 != 0 || (dirs != 1 && dirs != 2) || s < 0 || s >= T) return SPARCH_EINVAL;
+    if (!g_out || !y_state || !dpre || !y_prev || !dpre_step || (s > 0 && !rec)) return SPARCH_EINVAL;
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
+    if (!al16({g_out, y_state, rec, dpre, y_prev, dpre_step})) return SPARCH_EALIGN;
+    AnnArgs a{};
+    a.B = B; a.dirs = dirs; a.T = T; a.H = H; a.Bp = B * dirs;
+    a.n_ct = cdiv(H, CT); a.nkg = 4; a.n_rt_total = cdiv(a.Bp, RT); a.rt_base = 0; a.n_rt_launch = a.n_rt_total;
+    a.s_begin = s; a.s_end = s + 1;
+    a.g_out = g_out; a.y_in = y_state; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    a.dpre = dpre; a.y_prev = y_prev; a.rec_ext = rec; a.step_out = dpre_step;
+    return launch_ann_step<true>(act, a, (hipStream_t)stream);
 }

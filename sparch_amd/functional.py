@@ -112,6 +112,15 @@ def rec_steps_per_launch(T):
     return int(v) if v else T
 
 
+# Hidden sizes above this take the step path of the recurrent cells (the persistent kernels keep a (H x 32)
+# slice of V in registers, which stops fitting at H > 1024); SPARCH_REC_STEP_PATH=1 forces it at any size (tests).
+REC_PERSISTENT_MAX_H = 1024
+
+
+def rec_step_path(H):
+    return H > REC_PERSISTENT_MAX_H or os.environ.get("SPARCH_REC_STEP_PATH", "0") == "1"
+
+
 def _f32c(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
 
@@ -327,6 +336,25 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         if H % 4 != 0:
             raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
         V = p["V"]
+        if rec_step_path(H):
+            # One launch per time step, the recurrent product s_{t-1} @ V between the steps on the exact
+            # spike GEMM (3 bf16 planes of V, fp32 accumulate): same arithmetic as the persistent kernel.
+            vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
+            check(lib.sparch_vmask(H, ptr(V), ptr(vmask), _stream()), "sparch_vmask")
+            vmask_t = vmask.t().contiguous()              # (H_out, H_in): the NT operand
+            rec = gemm_nn(s0, vmask)                      # t = 0: s0 is uniform noise, not binary
+            s_step = torch.empty(Bp, H, dtype=torch.bfloat16, device=dev)
+            tok = timer.start(f"rec_cell_fwd_steps[{kind}]")
+            for t in range(T):
+                if t > 0:
+                    rec, _ = gemm_nt(s_step, vmask_t, spike_scale=1.0, a16=s_step)
+                check(lib.sparch_rec_cell_step_fwd(k, B, dirs, T, H, t, ptr(Wx), ptr(scale), ptr(shift),
+                                                   ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")),
+                                                   ptr(p.get("b")), ptr(rec), ptr(u0), ptr(w0), ptr(s0), theta,
+                                                   p_drop, seed, ptr(s_out), ptr(s16), ptr(u_save), ptr(w_save),
+                                                   ptr(count), ptr(s_step), _stream()), "sparch_rec_cell_step_fwd")
+            timer.stop(tok)
+            return s_out, count, (u_save, w_save), s16
         vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
         vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
         check(lib.sparch_vpack(H, ptr(V), 0, ptr(vpack), ptr(vmask), _stream()), "sparch_vpack")
@@ -366,19 +394,36 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
         timer.stop(tok)
     else:
         V = p["V"]
-        vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-        check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
         s_prev = torch.empty(Bp, T, H, dtype=torch.bfloat16, device=dev)  # bf16 0/1 plane
-        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
-        L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
-        tok = timer.start(f"rec_cell_bwd[{kind}]")
-        check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
-                                      ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
-                                      ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
-                                      ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
-                                      _stream()), "sparch_rec_cell_bwd")
-        timer.stop(tok)
+        if rec_step_path(H):
+            # reverse-time steps with dWx_{t+1} @ V^T between them (exact six-term split GEMM)
+            vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
+            check(lib.sparch_vmask(H, ptr(V), ptr(vmask), _stream()), "sparch_vmask")
+            dwx_step = torch.empty(Bp, H, dtype=torch.float32, device=dev)
+            rec = None
+            tok = timer.start(f"rec_cell_bwd_steps[{kind}]")
+            for t in range(T - 1, -1, -1):
+                if t + 1 < T:
+                    rec, _ = gemm_nt(dwx_step, vmask)     # rec[b,i] = sum_j dWx[b,j] Vm[i,j]
+                check(lib.sparch_rec_cell_step_bwd(k, B, dirs, T, H, t, ptr(g_out), ptr(g_rate), ptr(u_save),
+                                                   ptr(w_save), ptr(p["alpha"]), ptr(p.get("beta")),
+                                                   ptr(p.get("a")), ptr(p.get("b")), ptr(rec), ptr(u0), ptr(w0),
+                                                   ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(s_prev), ptr(ws),
+                                                   ptr(dwx_step), _stream()), "sparch_rec_cell_step_bwd")
+            timer.stop(tok)
+        else:
+            vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
+            nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+            tok = timer.start(f"rec_cell_bwd[{kind}]")
+            check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
+                                          ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
+                                          ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
+                                          ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
+                                          _stream()), "sparch_rec_cell_bwd")
+            timer.stop(tok)
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
         # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
         # (cell step 0 sits at original time 0 for the forward direction, T-1 for the flipped one)
@@ -491,8 +536,8 @@ class ReadoutLayerFn(torch.autograd.Function):
         x = _f32c(x)
         B, T, K = x.shape
         C = W.shape[0]
-        if C > 64:
-            raise ValueError("sparch_amd: readout layer supports at most 64 classes")
+        if C > 256:
+            raise ValueError(f"sparch_amd: the readout kernels handle at most 256 classes (got {C})")
         M = B * T
         x2 = x.view(M, K)
         x16 = cfg.get("in_spike16") if cfg.get("in_spike_scale") is not None else None
@@ -576,8 +621,8 @@ class ReadoutCellFn(torch.autograd.Function):
         _require_device(Wx, "Wx")
         Wx = _f32c(Wx)
         B, T, C = Wx.shape
-        if C > 64:
-            raise ValueError("sparch_amd: readout layer supports at most 64 classes")
+        if C > 256:
+            raise ValueError(f"sparch_amd: the readout kernels handle at most 256 classes (got {C})")
         out = torch.empty(B, C, dtype=torch.float32, device=Wx.device)
         u_save = torch.empty(B, T, C, dtype=torch.float32, device=Wx.device)
         check(lib.sparch_readout_fwd(B, T, C, ptr(Wx), None, None, ptr(alpha), ptr(u0), ptr(out), ptr(u_save),
@@ -741,27 +786,39 @@ class RNNLayerFn(torch.autograd.Function):
         x = _f32c(x)
         B, T, K = x.shape
         H = W.shape[0]
-        if H % 4 != 0 or H > 1024:
-            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0 and <= 1024")
+        if H % 4 != 0:
+            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
         M = B * T
         dev = x.device
         x2 = x.view(M, K)
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))             # anns.py:306
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)          # 309-311
-        vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-        check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream()), "sparch_vpack")       # y V^T, dense
         Bp = B * dirs
         y_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
         y_state = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
-        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
-        tok = timer.start("ann_rec_fwd[RNN]")
-        check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
-                                     ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state), ptr(chan),
-                                     nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
-              "sparch_ann_rec_fwd")
-        timer.stop(tok)
+        if rec_step_path(H):  # one launch per step, y_{t-1} V^T between the steps (exact six-term split GEMM)
+            y_step = torch.empty(Bp, H, dtype=torch.float32, device=dev)
+            rec = None
+            tok = timer.start("ann_rec_fwd_steps[RNN]")
+            for t in range(T):
+                if t > 0:
+                    rec, _ = gemm_nt(y_step, V)
+                check(lib.sparch_ann_rec_step_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, t, ptr(Wx_in), ptr(scale),
+                                                  ptr(shift), ptr(rec), cfg["p_drop"], cfg["seed"], ptr(y_out),
+                                                  ptr(y_state), ptr(y_step), _stream()), "sparch_ann_rec_step_fwd")
+            timer.stop(tok)
+        else:
+            vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # y V^T, dense
+            nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            tok = timer.start("ann_rec_fwd[RNN]")
+            check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
+                                         ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state),
+                                         ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T),
+                                         _stream()), "sparch_ann_rec_fwd")
+            timer.stop(tok)
         ctx.cfg, ctx.shape, ctx.nsaved = cfg, (B, T, K, H), nsaved
         ctx.save_for_backward(x2, W, nw, V, y_state, Wx_raw if norm in ("batchnorm", "layernorm") else None)
         return y_out
@@ -774,17 +831,31 @@ class RNNLayerFn(torch.autograd.Function):
         x2, W, nw, V, y_state, Wx_raw = ctx.saved_tensors
         M, Bp = B * T, B * dirs
         dev = x2.device
-        vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-        check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream()), "sparch_vpack")       # dpre V, dense
         dpre = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
         y_prev = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
-        nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
-        tok = timer.start("ann_rec_bwd[RNN]")
-        check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(vpack),
-                                     cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
-                                     ptr(status_word(dev)), rec_steps_per_launch(T), _stream()), "sparch_ann_rec_bwd")
-        timer.stop(tok)
+        g_y = _f32c(g_y)
+        if rec_step_path(H):
+            dpre_step = torch.empty(Bp, H, dtype=torch.float32, device=dev)
+            rec = None
+            tok = timer.start("ann_rec_bwd_steps[RNN]")
+            for s_ in range(T):
+                if s_ > 0:
+                    rec = gemm_nn(dpre_step, V)           # dpre_{t+1} V
+                check(lib.sparch_ann_rec_step_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, s_, ptr(g_y), ptr(y_state),
+                                                  ptr(rec), cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev),
+                                                  ptr(dpre_step), _stream()), "sparch_ann_rec_step_bwd")
+            timer.stop(tok)
+        else:
+            vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # dpre V, dense
+            nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            tok = timer.start("ann_rec_bwd[RNN]")
+            check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(g_y), ptr(y_state), ptr(vpack),
+                                         cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
+                                         ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                  "sparch_ann_rec_bwd")
+            timer.stop(tok)
         # dV[i][j] = sum over rows and steps of dpre[.,i] * y_{t-1}[.,j]   (V(y) = y V^T, anns.py:336)
         dV = gemm_tn(dpre.view(Bp * T, H), y_prev.view(Bp * T, H))
         if dirs == 2:  # both directions share the projection rows (anns.py:298-300)

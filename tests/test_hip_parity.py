@@ -267,6 +267,103 @@ def test_recurrent_cell_bit_exact_with_dyadic_V(kind, spl, Bp, T, H):
     assert torch.equal(s.cpu(), ref), float((s.cpu() != ref).float().mean())
 
 
+def _dyadic_cell_case(kind, Bp, T, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    V = torch.randint(-24, 25, (H, H), generator=g).float() / 64.0
+    Wx = torch.randn(Bp, T, H, generator=g) * 1.5 + 0.4
+    p = {"alpha": torch.rand(H, generator=g) * 0.2 + 0.78, "V": V}
+    if kind == "RadLIF":
+        p.update(beta=torch.rand(H, generator=g) * 0.05 + 0.95, a=torch.rand(H, generator=g) * 2.4 - 1.2,
+                 b=torch.rand(H, generator=g) * 2.4 - 0.2)
+    u0 = torch.rand(Bp, H, generator=g)
+    w0 = torch.rand(Bp, H, generator=g) if kind == "RadLIF" else None
+    s0 = (torch.rand(Bp, H, generator=g) < 0.3).float()
+    g_s = torch.randn(Bp, T, H, generator=g)
+    return Wx, p, u0, w0, s0, g_s
+
+
+def _run_cell(kind, Wx, p, u0, w0, s0, g_s):
+    Fn = _Fn()
+    pd = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+    Wxd = Wx.to(DEV).requires_grad_(True)
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), pd["V"],
+                               u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), None)
+    (s * g_s.to(DEV)).sum().backward()
+    Fn.check_status()
+    return s.detach().cpu(), Wxd.grad.cpu(), {k: v.grad.cpu() for k, v in pd.items()}
+
+
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+def test_recurrent_step_path_equals_persistent_kernels(kind, monkeypatch):
+    """The step path (one launch per time step, recurrent product between the steps on the exact split
+    GEMMs: what hidden sizes above 1024 use) against the persistent kernels at a size both handle, dyadic V:
+    identical spikes, dWx and gradients to fp32 rounding (the two differ only in summation order)."""
+    case = _dyadic_cell_case(kind, 40, 21, 132, 5)
+    s_a, dwx_a, g_a = _run_cell(kind, *case)
+    monkeypatch.setenv("SPARCH_REC_STEP_PATH", "1")
+    s_b, dwx_b, g_b = _run_cell(kind, *case)
+    assert s_a.sum() > 0 and torch.equal(s_a, s_b)
+    assert relmax(dwx_b.numpy(), dwx_a.numpy()) <= 1e-5
+    for k in g_a:
+        assert relmax(g_b[k].numpy(), g_a[k].numpy()) <= 1e-5, k
+
+
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+def test_recurrent_cell_hidden_size_above_1024_vs_oracle(kind):
+    """The reference accepts any nb_hiddens (snns.py:608-661).  H = 1536 (V slice no longer register-resident:
+    step path), dyadic V: spikes bit-equal to the oracle, gradients (oracle autograd) to 2e-4 of max-abs."""
+    Wx, p, u0, w0, s0, g_s = _dyadic_cell_case(kind, 5, 12, 1536, 9)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Wxr = Wx.clone().requires_grad_(True)
+    ref = orc.spiking_cell(kind, Wxr, pr, u0, w0, s0)
+    (ref * g_s).sum().backward()
+    s, dwx, grads = _run_cell(kind, Wx, p, u0, w0, s0, g_s)
+    assert ref.sum() > 0 and torch.equal(s, ref.detach())
+    assert relmax(dwx.numpy(), Wxr.grad.numpy()) <= 2e-4
+    for k in grads:
+        assert relmax(grads[k].numpy(), pr[k].grad.numpy()) <= 2e-4, k
+    assert float(torch.diag(grads["V"]).abs().max()) == 0.0
+
+
+def test_snn_hidden_size_2048_and_200_classes_runs(sp):
+    """--nb_hiddens 2048 (used to fail with 'invalid argument') and a 200-class readout: one
+    training step of RadLIF [2048, 2048, 200]; invariants of the softmax-sum readout and finite gradients."""
+    B, T, C = 8, 10, 40
+    torch.manual_seed(3)
+    net = sp.SNN((B, None, C), [2048, 2048, 200], neuron_type="RadLIF", dropout=0.1).to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, 200, (B,), generator=g).to(DEV)
+    out, rates = net(x)
+    torch.nn.functional.cross_entropy(out, y).backward()
+    _Fn().check_status()
+    np.testing.assert_allclose(out.detach().sum(1).cpu().numpy(), np.full(B, T, np.float32), rtol=1e-4)
+    assert tuple(rates.shape) == (4096,) and float(rates.detach().mean()) > 0
+    for k, v in net.named_parameters():
+        assert bool(torch.isfinite(v.grad).all()), k
+    assert float(net.snn[0].V.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("C", [100, 200])
+def test_readout_cell_more_than_64_classes_vs_oracle(C):
+    Fn = _Fn()
+    B, T = 6, 150
+    g = torch.Generator().manual_seed(C)
+    Wx = torch.randn(B, T, C, generator=g) * 2.0
+    alpha = torch.rand(C, generator=g) * 0.2 + 0.78
+    u0 = torch.rand(B, C, generator=g)
+    g_out = torch.randn(B, C, generator=g)
+    Wr, ar = Wx.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref = orc.readout_cell(Wr, ar, u0)
+    (ref * g_out).sum().backward()
+    Wd, ad = Wx.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+    out = Fn.ReadoutCellFn.apply(Wd, ad, u0.to(DEV))
+    (out * g_out.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    assert relmax(Wd.grad.cpu().numpy(), Wr.grad.numpy()) <= 2e-4
+    assert relmax(ad.grad.cpu().numpy(), ar.grad.numpy()) <= 2e-4
+
+
 @pytest.mark.parametrize("kind,B,T,H", [("adLIF", 5, 17, 64), ("LIF", 33, 9, 128), ("RadLIF", 5, 33, 64),
                                         ("RLIF", 40, 21, 132), ("RadLIF", 48, 40, 1024)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.2])
@@ -1008,6 +1105,44 @@ def test_rnn_layer_vs_oracle_larger_and_chunked(bidir, H, monkeypatch):
         assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
         for k in g0:
             assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.gpu
+def test_rnn_layer_hidden_size_above_1024_vs_oracle(monkeypatch):
+    """RNN baseline with H = 1536 (step path) against the oracle, and the step path against the persistent kernel
+    at H = 128 (same arithmetic up to summation order)."""
+    from oracle import ann_oracle as ao
+    from sparch_amd.anns import RNNLayer
+
+    def run(H, B, T, C, bidir, step):
+        torch.manual_seed(21)
+        layer = RNNLayer(C, H, B, dropout=0.0, normalization="batchnorm", use_bias=False, bidirectional=bidir)
+        g = torch.Generator().manual_seed(22)
+        x = torch.randn(B, T, C, generator=g)
+        gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g)
+        p = {"ann.0." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+             for k, v in layer.state_dict().items() if "num_batches" not in k}
+        xr = x.clone().requires_grad_(True)
+        ref = ao.hidden_layer("RNN", xr, p, "ann.0", "batchnorm", bidir, training=True, running=None)
+        (ref * gy).sum().backward()
+        monkeypatch.setenv("SPARCH_REC_STEP_PATH", "1" if step else "0")
+        layer = layer.to(DEV).train()
+        xd = x.to(DEV).requires_grad_(True)
+        y = layer(xd)
+        (y * gy.to(DEV)).sum().backward()
+        _Fn().check_status()
+        got = {k: v.grad.cpu() for k, v in layer.named_parameters()}
+        return y.detach().cpu(), xd.grad.cpu(), got, ref.detach(), xr.grad, {k[6:]: v.grad for k, v in p.items() if v.grad is not None}
+
+    y, dx, g, ref, dxr, gr = run(1536, 6, 9, 40, False, False)
+    assert relmax(y.numpy(), ref.numpy()) <= 2e-5 and relmax(dx.numpy(), dxr.numpy()) <= 2e-4
+    for k in g:
+        assert relmax(g[k].numpy(), gr[k].numpy()) <= 2e-4, k
+    ya, dxa, ga, *_ = run(128, 40, 11, 32, True, False)
+    yb, dxb, gb, *_ = run(128, 40, 11, 32, True, True)
+    assert relmax(yb.numpy(), ya.numpy()) <= 1e-5 and relmax(dxb.numpy(), dxa.numpy()) <= 1e-5
+    for k in ga:
+        assert relmax(gb[k].numpy(), ga[k].numpy()) <= 2e-5, k
 
 
 @pytest.mark.gpu
