@@ -144,13 +144,14 @@ int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const flo
 /* Train: finish the statistics from colstat_ws (n_tiles partial rows, count = M rows,
  * `dup` = 2 when a bidirectional layer sees every row twice: running_var uses
  * n = dup*M), write scale = gamma*invstd, shift = beta - mean*scale, save mean/invstd,
- * update running stats in place (momentum m, unbiased variance).
+ * update running stats in place (momentum m, unbiased variance) — unless the device word
+ * skip_if_nonzero (nullable; the recurrent kernels' status word) is non-zero.
  * Eval (training = 0): scale/shift from running stats; colstat_ws ignored.           */
 int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const float* colstat_ws,
                        const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float momentum, float eps, int training,
                        float* scale, float* shift, float* save_mean, float* save_invstd,
-                       void* stream);
+                       const uint32_t* skip_if_nonzero, void* stream);
 
 /* Column sums of dy and dy*xhat over M rows (xhat = (x-mean)*invstd), partials in ws
  * (2 * ceil(M/256) * H floats), finished into dgamma[H], dbeta[H].                   */
@@ -381,11 +382,13 @@ int sparch_gate_step(int mode, int B, int dirs, int T, int H, int t, const float
  * One launch for the whole parameter list; arithmetic identical, operation by operation, to
  * torch.optim.Adam's default path (see optim.hip).  `params`, `grads`, `exp_avg`, `exp_avg_sq` are HOST
  * arrays of n_tensors DEVICE pointers, `numel` a host array of element counts.
- * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t): formed by the caller in double precision. */
+ * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t): formed by the caller in double precision.
+ * skip_if_nonzero (nullable): a device word, e.g. the recurrent kernels' status word — when it is non-zero
+ * the step leaves parameters and moments untouched (a timed-out step must not be applied; no host sync). */
 int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                      float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
-                     float weight_decay, void* stream);
+                     float weight_decay, const uint32_t* skip_if_nonzero, void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,7 @@ PROTOTYPES = {
     "sparch_gemm_auto_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P,
                                     c_size_t, P]),
     "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
-                                   P, P, P, P, P]),
+                                   P, P, P, P, P, P]),
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sparch_bn_bwd_reduce": (c_int, [c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     "sparch_bn_bwd_apply": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P]),
@@ -96,7 +96,7 @@ PROTOTYPES = {
     "sparch_ann_rec_step_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, c_uint64, P, P, P,
                                         P]),
     "sparch_gate_step": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, c_uint64, P]),
-    "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P, P]),
 }
 
 

@@ -27,13 +27,25 @@ def _make_norm(layer, name, normalization, size):
     return False
 
 
+_ANN_KINDS = ("MLP", "RNN", "LiGRU", "GRU")
+
+
 class ANN(nn.Module):
-    """anns.py:19-146.  forward(x (B,T,C)) -> (out, None): (B,classes) with the readout layer, else (B,T,H)."""
+    """Stack of non-spiking baseline layers (reference ANN, anns.py:19-146).
+
+    forward(x: (batch, time, feat) or 4-D (batch, time, feat, channel)) -> (out, None): out is
+    (batch, classes) with the readout layer, else (batch, time, feats); the None stands where SNN returns
+    firing rates, so that a trainer can treat both alike (anns.py:146)."""
 
     def __init__(self, input_shape, layer_sizes, ann_type="MLP", dropout=0.0, normalization="batchnorm",
                  use_bias=False, bidirectional=False, use_readout_layer=True):
         super().__init__()
-        self.reshape = True if len(input_shape) > 3 else False
+        if ann_type not in _ANN_KINDS:
+            raise ValueError(f"Invalid ann type {ann_type}")
+        if bidirectional and ann_type == "MLP":
+            raise ValueError("MLP cannot be bidirectional.")
+        # attributes callers and checkpoints of the reference see
+        self.reshape = len(input_shape) > 3
         self.input_size = float(torch.prod(torch.tensor(input_shape[2:])))
         self.batch_size = input_shape[0]
         self.layer_sizes = layer_sizes
@@ -46,39 +58,33 @@ class ANN(nn.Module):
         self.bidirectional = bidirectional
         self.use_readout_layer = use_readout_layer
         self.is_snn = False
-        if ann_type not in ["MLP", "RNN", "LiGRU", "GRU"]:
-            raise ValueError(f"Invalid ann type {ann_type}")
-        if bidirectional and ann_type == "MLP":
-            raise ValueError("MLP cannot be bidirectional.")
         self.ann = self._init_layers()
 
     def _init_layers(self):
-        ann = nn.ModuleList([])
-        input_size = self.input_size
-        ann_class = self.ann_type + "Layer"
-        num_hidden_layers = self.num_layers - 1 if self.use_readout_layer else self.num_layers
-        for i in range(num_hidden_layers):
-            layer = globals()[ann_class](input_size=input_size, hidden_size=self.layer_sizes[i],
-                                         batch_size=self.batch_size, dropout=self.dropout,
-                                         normalization=self.normalization, use_bias=self.use_bias,
-                                         bidirectional=self.bidirectional)
-            layer._layer_index = i
-            ann.append(layer)
-            input_size = self.layer_sizes[i] * (1 + self.bidirectional)
+        layer_cls = _HIDDEN_CLASSES[self.ann_type]
+        hidden_sizes = self.layer_sizes[:-1] if self.use_readout_layer else self.layer_sizes
+        width = 1 + int(self.bidirectional)
+        layers, fan_in = [], self.input_size
+        for index, size in enumerate(hidden_sizes):  # creation order = the reference's RNG draw order
+            layer = layer_cls(input_size=fan_in, hidden_size=size, batch_size=self.batch_size,
+                              dropout=self.dropout, normalization=self.normalization, use_bias=self.use_bias,
+                              bidirectional=self.bidirectional)
+            layer._layer_index = index  # decorrelates the dropout masks of the layers
+            layers.append(layer)
+            fan_in = size * width
         if self.use_readout_layer:
-            ann.append(ReadoutLayerANN(input_size=input_size, output_size=self.layer_sizes[-1],
-                                       normalization=self.normalization, use_bias=self.use_bias))
-        return ann
+            layers.append(ReadoutLayerANN(input_size=fan_in, output_size=self.num_outputs,
+                                          normalization=self.normalization, use_bias=self.use_bias))
+        return nn.ModuleList(layers)
 
     def forward(self, x):
         if self.reshape:
-            if x.ndim == 4:
-                x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
-            else:
-                raise (NotImplementedError)
-        for ann_lay in self.ann:
-            x = ann_lay(x)
-        return x, None  # so that same as SNN (anns.py:146)
+            if x.ndim != 4:
+                raise NotImplementedError
+            x = x.flatten(2)
+        for layer in self.ann:
+            x = layer(x)
+        return x, None
 
 
 class _ANNLayer(nn.Module):
@@ -171,6 +177,10 @@ class RNNLayer(_RecurrentANNLayer):
     """anns.py:230-339: y_t = sigmoid(norm(W x)_t + V y_{t-1}) on the persistent dense recurrent kernel."""
     KIND = "RNN"
 
+    @property
+    def uses_persistent_kernel(self):  # what sparch_amd.dp keys its all-reduce policy on
+        return not Fn.rec_step_path(self.hidden_size)
+
     def forward(self, x):
         Fn._require_device(x, "input")
         dirs = self._rows(x)
@@ -206,3 +216,6 @@ class ReadoutLayerANN(_ANNLayer):
         nw, nb, rm, rv = self._norm_args()
         cfg = {"normalization": self.normalization, "training": self.training, "running_mean": rm, "running_var": rv}
         return Fn.ReadoutANNFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)
+
+
+_HIDDEN_CLASSES = {"MLP": MLPLayer, "RNN": RNNLayer, "LiGRU": LiGRULayer, "GRU": GRULayer}

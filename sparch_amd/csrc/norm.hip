@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_ti
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd) {
+                                   float* __restrict__ save_invstd, const uint32_t* __restrict__ skip_if_nonzero) {
     __shared__ double red[CS_LANES][CS_COLS];
     const int h = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1));
     const bool ok = h < H;
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_ti
         var = (float)v;
         const double n = (double)M * (double)dup;
         const float unbiased = (float)(v * (n / (n - 1.0)));
-        rmean[h] = momentum * mean + (1.0f - momentum) * rmean[h];
-        rvar[h] = momentum * unbiased + (1.0f - momentum) * rvar[h];
+        if (!(skip_if_nonzero && *skip_if_nonzero != 0u)) {  // a timed-out step does not move the running statistics
+            rmean[h] = momentum * mean + (1.0f - momentum) * rmean[h];
+            rvar[h] = momentum * unbiased + (1.0f - momentum) * rvar[h];
+        }
     } else {
         mean = rmean[h];
         var = rvar[h];
@@ -282,13 +284,13 @@ extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const floa
                                   const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, int training,
                                   float* scale, float* shift, float* save_mean, float* save_invstd,
-                                  void* stream) {
+                                  const uint32_t* skip_if_nonzero, void* stream) {
     SPARCH_ENTER();
     if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
     if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, (hipStream_t)stream, H, M,
                        n_tiles, dup, colstat_ws, gamma, beta, running_mean, running_var, momentum, eps,
-                       training, scale, shift, save_mean, save_invstd);
+                       training, scale, shift, save_mean, save_invstd, skip_if_nonzero);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

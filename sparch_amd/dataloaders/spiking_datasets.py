@@ -78,8 +78,11 @@ class SpikingDataset(Dataset):
 
 
 def load_shd_or_ssc(dataset_name, data_folder, split, batch_size, nb_steps=100, shuffle=True, workers=0,
-                    h5_file=None, device="cuda"):
-    """spiking_datasets.py:90-140."""
+                    h5_file=None, device="cuda", rank=0, world=1, seed=0):
+    """spiking_datasets.py:90-140.  rank / world (data-parallel runs; not in the reference, which is single
+    device): every rank reads the same file and draws a disjoint 1/world share of each epoch's (shuffled)
+    sample order through a DistributedSampler — call `loader.sampler.set_epoch(e)` per epoch; `batch_size`
+    is the PER-RANK batch."""
     if dataset_name not in ["shd", "ssc"]:
         raise ValueError(f"Invalid dataset name {dataset_name}")
     if split not in ["train", "valid", "test"]:
@@ -92,5 +95,11 @@ def load_shd_or_ssc(dataset_name, data_folder, split, batch_size, nb_steps=100, 
                          "(the reference's default)")
     dataset = SpikingDataset(dataset_name, data_folder, split, nb_steps, h5_file=h5_file, device=device)
     logging.info(f"Number of examples in {split} set: {len(dataset)}")
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
+        return DataLoader(dataset, batch_size=batch_size, collate_fn=dataset.generateBatch, sampler=sampler,
+                          num_workers=0, pin_memory=False)
     return DataLoader(dataset, batch_size=batch_size, collate_fn=dataset.generateBatch, shuffle=shuffle,
                       num_workers=0, pin_memory=False)

@@ -12,13 +12,18 @@ the last one lands, flattens the bucket.  Two launch policies:
 
   * overlap (models WITHOUT recurrent layers): the bucket's all-reduce is launched at once, async, and
     runs on RCCL's stream underneath the next (earlier) layer's backward;
-  * deferred (models with RLIF / RadLIF / RNN layers — the default there): ONE all-reduce of all buckets
-    at the end of backward.  The recurrent cells are persistent kernels whose workgroups wait for each other
-    and need every CU of the GPU (one workgroup per CU, the whole register file): an RCCL kernel that holds
-    a few CUs while it waits for a peer rank keeps such a grid from becoming co-resident, and a peer whose
-    own persistent kernel got the GPU first keeps ITS RCCL kernel from starting — a rank that is slightly
-    ahead would then lose up to a whole recurrent launch (1.5 ms) per bucket.  The deferred collective costs
-    a fixed ~0.1-0.2 ms (15.6 MB over 7 xGMI links) instead.  `SPARCH_DP_OVERLAP=0/1` overrides.
+  * deferred (models whose layers run the PERSISTENT recurrent kernels — RLIF / RadLIF / RNN up to 1024
+    hidden units; keyed on the layers' `uses_persistent_kernel`, not on having a V matrix: LiGRU / GRU and
+    the large-H step path launch per time step and overlap like everything else — AND whose persistent grid
+    needs the whole GPU): ONE all-reduce of all buckets at the end of backward.  Those kernels' workgroups
+    wait for each other and need one CU each: an RCCL kernel that holds a few CUs while it waits for a peer
+    rank keeps a 256-workgroup grid from becoming co-resident, and a peer whose own persistent kernel got
+    the GPU first keeps ITS RCCL kernel from starting — a rank that is slightly ahead would then lose up to
+    a whole recurrent launch (1.3 ms) per bucket.  The deferred collective costs a fixed ~0.1-0.2 ms
+    (15.6 MB over 7 xGMI links) instead.  When the per-rank batch leaves CUs free (`rows_per_rank` given:
+    ceil(rows/32) row tiles x H/32 column tiles <= CUs - RCCL_CU_RESERVE, e.g. any strong-scaling shard of
+    the headline batch), the grid and RCCL's channels fit side by side and the overlap policy is used.
+    `SPARCH_DP_OVERLAP=0/1` overrides.
 
 `finish()` waits, averages and hands the gradients to `optimizer.step()`.
 
@@ -29,18 +34,43 @@ import torch
 import torch.distributed as dist
 
 
+RCCL_CU_RESERVE = 32  # CUs left to RCCL's channel kernels when a persistent grid runs beside them
+
+
+def persistent_grid_fills_gpu(layers, rows_per_rank, cus=256):
+    """True if some layer's persistent recurrent launch would occupy (nearly) every CU: n_row_tiles x
+    n_column_tiles workgroups, one per CU, against cus - RCCL_CU_RESERVE.  Unknown batch -> assume it does."""
+    for lay in layers:
+        if not getattr(lay, "uses_persistent_kernel", False):
+            continue
+        if rows_per_rank is None:
+            return True
+        rows = rows_per_rank * (2 if getattr(lay, "bidirectional", False) else 1)
+        n_rt, n_ct = -(-rows // 32), -(-int(lay.hidden_size) // 32)
+        if n_ct * min(n_rt, max(1, cus // n_ct)) > cus - RCCL_CU_RESERVE:
+            return True
+    return False
+
+
 class GradAllReducer:
-    def __init__(self, module, process_group=None, buckets=None, overlap=None):
+    def __init__(self, module, process_group=None, buckets=None, overlap=None, rows_per_rank=None):
         """buckets: list of lists of parameters (default: one bucket per child of `module.snn` / `module.ann`,
         or a single bucket for arbitrary modules).  Buckets fire in whatever order backward
-        completes them (readout first, input layer last).  overlap: None = by model (see module docstring)."""
+        completes them (readout first, input layer last).  overlap: None = by model and per-rank batch
+        (`rows_per_rank`), see the module docstring."""
         import os
 
         self.group = process_group
         layers_all = getattr(module, "snn", None) or getattr(module, "ann", None) or []
         if overlap is None:
             env = os.environ.get("SPARCH_DP_OVERLAP", "")
-            overlap = (env == "1") if env in ("0", "1") else not any(hasattr(lay, "V") for lay in layers_all)
+            if env in ("0", "1"):
+                overlap = env == "1"
+            else:
+                cus = 256
+                if torch.cuda.is_available():
+                    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+                overlap = not persistent_grid_fills_gpu(layers_all, rows_per_rank, cus)
         self.overlap = bool(overlap)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if buckets is None:

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from torch.optim.lr_scheduler import ReduceLROnPlateau
 
 from . import dp, optim
+from . import functional as Fn
 from .functional import check_status, fbank
 from .parsers import print_model_options, print_training_options
 from .anns import ANN
@@ -85,6 +86,7 @@ class Experiment:
         self.synthetic = getattr(args, "synthetic", False)
         self.synthetic_batches = getattr(args, "synthetic_batches", 8)
         self.seq_len = getattr(args, "seq_len", 100)
+        self.sync_bn = getattr(args, "sync_bn", False)
 
         self.rank, self.world, self.local_rank = dp.init_from_env()
         self.is_main = self.rank == 0
@@ -109,7 +111,14 @@ class Experiment:
         self.scheduler = ReduceLROnPlateau(optimizer=self.opt, mode="max", factor=self.scheduler_factor,
                                            patience=self.scheduler_patience, min_lr=1e-6)
         self.loss_fn = nn.CrossEntropyLoss()
-        self.reducer = dp.GradAllReducer(self.net) if self.world > 1 else None
+        self.reducer = None
+        if self.world > 1:
+            self.reducer = dp.GradAllReducer(self.net, rows_per_rank=self.batch_size // self.world)
+            logging.info(f"Gradient all-reduce: {self.reducer.bytes_per_step / 1e6:.2f} MB per step, "
+                         f"{'overlapped with backward' if self.reducer.overlap else 'one collective after backward'}")
+            if self.sync_bn:
+                Fn.SYNC_BN = {"group": None, "world": self.world}
+                logging.info("BatchNorm statistics are exchanged between ranks (--sync_bn)")
         self.status_check_every = 64  # steps between reads of the kernels' status word (a host sync)
 
     # ---------------------------------------------------------------------------------- driver
@@ -156,8 +165,19 @@ class Experiment:
                 "bias" if self.use_bias else "nobias", "bdir" if self.bidirectional else "udir",
                 "reg" if self.use_regularizers else "noreg", f"lr{self.lr}"])
             exp_folder = "exp/test_exps/" + name.replace(".", "_")
-        if not self.use_pretrained_model and os.path.exists(exp_folder) and self.is_main:
+        # decided on EVERY rank (the ranks of one node see the same file system) before any collective: a
+        # rank-0-only exception would leave the others waiting in the parameter broadcast
+        exists = (not self.use_pretrained_model) and os.path.exists(exp_folder)
+        if self.world > 1:
+            flag = torch.tensor([int(exists)])
+            if torch.distributed.get_backend() != "gloo":
+                flag = flag.cuda()
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            exists = bool(int(flag.item()))
+        if exists:
             raise FileExistsError(errno.EEXIST, os.strerror(errno.EEXIST), exp_folder)
+        if self.world > 1:  # nobody creates the folder while a peer is still looking for it
+            torch.distributed.barrier()
         self.log_dir = exp_folder + "/log/"
         self.checkpoint_dir = exp_folder + "/checkpoints/"
         if self.is_main:
@@ -190,14 +210,11 @@ class Experiment:
                 raise RuntimeError(
                     "sparch_amd: the file-based HD/SC (torchaudio) loader of the reference is not part of this "
                     "build (no torchaudio offline); run with --synthetic 1")
-            if self.world > 1:
-                raise RuntimeError("sparch_amd: file-based datasets are single-process in this round "
-                                   "(no per-rank sampler yet); use --synthetic 1 for data-parallel runs")
             from .dataloaders.spiking_datasets import load_shd_or_ssc  # exp.py:224-252 (needs h5py + the files)
 
-            def ld(split, shuffle):
+            def ld(split, shuffle):  # data-parallel: each rank draws its 1/world share of every epoch
                 return load_shd_or_ssc(self.dataset_name, self.data_folder, split, per_rank, nb_steps=100,
-                                       shuffle=shuffle, device=self.device)
+                                       shuffle=shuffle, device=self.device, rank=self.rank, world=self.world)
 
             self.train_loader, self.valid_loader = ld("train", True), ld("valid", False)
             if self.dataset_name == "ssc":
@@ -256,6 +273,8 @@ class Experiment:
     def train_one_epoch(self, e):
         start = time.time()
         self.net.train()
+        if hasattr(getattr(self.train_loader, "sampler", None), "set_epoch"):
+            self.train_loader.sampler.set_epoch(e)  # per-rank shards of a fresh permutation every epoch
         losses, accs, sizes = [], [], []
         epoch_spike_rate = 0
         seen = 0
@@ -283,8 +302,8 @@ class Experiment:
             sizes.append(y.shape[0])
             seen += x.shape[0] * x.shape[1]
             if (step + 1) % self.status_check_every == 0:
-                check_status(self.device)
-        check_status(self.device)
+                self._check_kernels(e, step)
+        self._check_kernels(e, step)
         losses = torch.stack(losses).cpu().numpy().astype(np.float64) if losses else np.zeros(0)
         accs = (torch.stack(accs).cpu().numpy().astype(np.float64) / np.asarray(sizes, np.float64)) if accs else np.zeros(0)
         logging.info(f"Epoch {e}: lr={self.opt.param_groups[-1]['lr']}")
@@ -296,6 +315,16 @@ class Experiment:
         elapsed = time.time() - start
         logging.info(f"Epoch {e}: train elapsed time={str(timedelta(seconds=elapsed))}")
         logging.info(f"Epoch {e}: train throughput={self.world * seen / elapsed:.0f} timesteps*samples/s")
+
+    def _check_kernels(self, e, step):
+        """Read the recurrent kernels' status word.  After an in-kernel timeout (the persistent grid could
+        not become co-resident: GPU shared or partitioned) the steps since the last check were no-ops on the
+        device (the optimizer and the BatchNorm statistics skip themselves while the word is raised); this
+        process now continues with one launch per time step — new launches, same process."""
+        if check_status(self.device, on_timeout="degrade"):
+            logging.warning(f"Epoch {e}, step {step}: {Fn._TIMEOUT_TEXT}  Steps since the previous check were "
+                            "skipped; continuing with one kernel launch per time step "
+                            "(SPARCH_REC_STEPS_PER_LAUNCH=1 behaviour).")
 
     def _eval_epoch(self, loader):
         losses, accs, sizes = [], [], []

@@ -26,6 +26,13 @@ USE_SPIKE16 = os.environ.get("SPARCH_SPIKE16", "1") != "0"
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
 
 BN_MOMENTUM = 0.05  # snns.py:240
+# SyncBN for data-parallel runs (off by default = standard DDP semantics: per-rank statistics).
+# {"group": process group or None, "world": n}: BatchNorm then normalises with the statistics of the GLOBAL
+# batch — forward: every rank's per-tile (sum x, sum x^2) partials are all-gathered and finished in one pass
+# (same fp64 reduction as the single-device path, so world ranks x B/world rows reproduce one device with B
+# rows up to summation order); backward: (sum dy, sum dy*xhat) are all-reduced for dx, the affine
+# parameters' own gradients stay local sums (the gradient all-reduce averages them like every other one).
+SYNC_BN = None
 NORM_EPS = 1e-5
 
 ALPHA_LIM = (0.8187307530779818, 0.9607894391523232)  # exp(-1/5), exp(-1/25)   snns.py:229
@@ -94,22 +101,51 @@ def status_word(device):
     return _status[key]
 
 
-def check_status(device="cuda"):
-    """Synchronising check of the persistent-kernel status word (call at a sync point)."""
+_TIMEOUT_TEXT = (
+    "recurrent cell kernel: in-kernel wait timed out (SPARCH_ETIMEOUT).  The persistent kernels need one "
+    "workgroup per CU resident at the same time; if the GPU is shared with another process (or partitioned) "
+    "they cannot all become resident.  The results of the affected step are invalid (the optimizer step and "
+    "the BatchNorm running statistics skip themselves on the device while the status word is raised).")
+_degraded = set()  # device indices whose recurrent kernels now run one launch per time step
+
+
+def poll_status(device="cuda"):
+    """Synchronising read of the persistent-kernel status word; clears it.  True = a wait timed out."""
     w = status_word(device)
     if int(w[0].item()) != 0:
         w.zero_()
-        raise _capi.SparchHipError(
-            "recurrent cell kernel: in-kernel wait timed out (SPARCH_ETIMEOUT).  The persistent kernels need one "
-            "workgroup per CU resident at the same time; if the GPU is shared with another process (or "
-            "partitioned), set SPARCH_REC_STEPS_PER_LAUNCH=1 (one launch per time step, no waiting inside).  "
-            "The results of the affected step are invalid.")
+        return True
+    return False
+
+
+def degrade(device="cuda"):
+    """From now on this process runs the recurrent cells with one launch per time step on `device` (nothing
+    waits inside a launch, any CU share works).  New launches only — the process is never re-executed."""
+    _degraded.add(torch.device(device).index or 0)
+
+
+def check_status(device="cuda", on_timeout="raise"):
+    """Synchronising check of the persistent-kernel status word (call at a sync point).
+    on_timeout = "raise": SparchHipError.  "degrade": switch this process to one launch per time step
+    (see `degrade`) and return True, so that a trainer can log the lost step and carry on."""
+    if not poll_status(device):
+        return False
+    if on_timeout == "degrade":
+        degrade(device)
+        return True
+    raise _capi.SparchHipError(_TIMEOUT_TEXT + "  Set SPARCH_REC_STEPS_PER_LAUNCH=1 (one launch per time step, "
+                               "no waiting inside) to run on a shared GPU.")
 
 
 def rec_steps_per_launch(T):
-    """Time steps per persistent launch of the recurrent cell kernels (default: whole sequence)."""
+    """Time steps per persistent launch of the recurrent cell kernels (default: whole sequence; 1 after a
+    timeout put the current device into degraded mode)."""
     v = os.environ.get("SPARCH_REC_STEPS_PER_LAUNCH", "")
-    return int(v) if v else T
+    if v:
+        return int(v)
+    if _degraded and torch.cuda.is_available() and torch.cuda.current_device() in _degraded:
+        return 1
+    return T
 
 
 # Hidden sizes above this take the step path of the recurrent cells (the persistent kernels keep a (H x 32)
@@ -258,10 +294,19 @@ class _Norm:
             shift = torch.empty(H, dtype=torch.float32, device=dev)
             mean = torch.empty(H, dtype=torch.float32, device=dev)
             invstd = torch.empty(H, dtype=torch.float32, device=dev)
-            check(lib.sparch_bn_finalize(H, M, (M + 127) // 128, dup, ptr(colstat), ptr(weight), ptr(bias),
+            n_tiles, rows = (M + 127) // 128, M
+            if training and SYNC_BN is not None and SYNC_BN["world"] > 1:
+                import torch.distributed as dist
+
+                world = SYNC_BN["world"]
+                parts = [torch.empty_like(colstat) for _ in range(world)]
+                dist.all_gather(parts, colstat, group=SYNC_BN["group"])
+                colstat = torch.stack([q.view(2, n_tiles, H) for q in parts], dim=1).reshape(-1)  # (2, world*tiles, H)
+                n_tiles, rows = n_tiles * world, M * world
+            check(lib.sparch_bn_finalize(H, rows, n_tiles, dup, ptr(colstat), ptr(weight), ptr(bias),
                                          ptr(running_mean), ptr(running_var), BN_MOMENTUM, NORM_EPS,
                                          int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                         _stream()), "sparch_bn_finalize")
+                                         ptr(status_word(dev)), _stream()), "sparch_bn_finalize")
             return Wx_raw, scale, shift, (mean, invstd)
         if mode == "layernorm":
             y = torch.empty_like(Wx_raw)
@@ -285,7 +330,14 @@ class _Norm:
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_bn_bwd_reduce(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(dgamma),
                                            ptr(dbeta), ptr(ws), nbytes, _stream()), "sparch_bn_bwd_reduce")
-            if training:
+            if training and SYNC_BN is not None and SYNC_BN["world"] > 1:
+                import torch.distributed as dist
+
+                red = torch.stack([dgamma, dbeta])
+                dist.all_reduce(red, op=dist.ReduceOp.SUM, group=SYNC_BN["group"])
+                red.mul_(1.0 / SYNC_BN["world"])  # the apply kernel divides by the LOCAL row count
+                cg, cb = red[0], red[1]
+            elif training:
                 cg, cb = dgamma, dbeta
             else:  # fixed statistics: dx = dy * gamma * invstd, i.e. the batch-coupling terms vanish
                 cg = torch.zeros(H, dtype=torch.float32, device=dev)

@@ -14,7 +14,7 @@ import math
 import torch
 
 from ._capi import check, lib
-from .functional import _stream
+from .functional import _stream, status_word
 
 
 class Adam(torch.optim.Optimizer):
@@ -75,5 +75,9 @@ class Adam(torch.optim.Optimizer):
         a_m = arr(*[self.state[p]["exp_avg"].data_ptr() for p in ps])
         a_v = arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps])
         a_n = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+        # guarded by the recurrent kernels' status word: after an in-kernel timeout (invalid gradients) the
+        # step is a no-op on the device until check_status() has reported it and cleared the word
+        skip = status_word(ps[0].device)
         check(lib.sparch_adam_step(n, a_p, a_g, a_m, a_v, a_n, float(step_size), float(beta1), float(beta2),
-                                   float(bc2_sqrt), float(eps), float(weight_decay), _stream()), "sparch_adam_step")
+                                   float(bc2_sqrt), float(eps), float(weight_decay), skip.data_ptr(), _stream()),
+              "sparch_adam_step")

@@ -58,6 +58,8 @@ EXTRA_FLAGS = [
     ("synthetic", strtobool, False, None, "[sparch_amd] use synthetic data of the dataset's shape (no files needed)."),
     ("synthetic_batches", int, 8, None, "[sparch_amd] batches per synthetic epoch."),
     ("seq_len", int, 100, None, "[sparch_amd] time steps of synthetic spiking inputs (loaders bin to 100)."),
+    ("sync_bn", strtobool, False, None, "[sparch_amd] data-parallel runs: BatchNorm over the GLOBAL batch "
+                                        "(statistics exchanged between ranks) instead of per rank."),
 ]
 
 

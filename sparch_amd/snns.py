@@ -41,6 +41,22 @@ class SpikeFunctionBoxcar(torch.autograd.Function):
         return grad_spikes * inside.to(grad_spikes.dtype)
 
 
+def _tag_spikes(s, scale, s16):
+    """Mark `s` as a spike train of ours (entries 0 or `scale`, `s16` the same spikes as a bf16 0/1 plane) so
+    that the next layer can take the exact spike GEMMs.  The tag carries the tensor's version counter: an
+    in-place edit between the layers (mul_, masked fill, slice assignment) invalidates it."""
+    s._sparch_spike_tag = (s._version, tuple(s.shape), float(scale), s16)
+
+
+def _spike_tag(x):
+    """(scale, s16) if x still is the untouched output of one of our spiking layers, else (None, None):
+    the layer then treats x as an arbitrary real-valued input (device-gated exact path / dense GEMM)."""
+    tag = getattr(x, "_sparch_spike_tag", None)
+    if tag is None or tag[0] != x._version or tag[1] != tuple(x.shape):
+        return None, None
+    return tag[2], tag[3]
+
+
 def _rand_to(rows, cols, device):
     """torch.rand from the global CPU generator (the reference's source of initial states), staged
     in pinned memory and copied asynchronously so the host does not stall once per layer."""
@@ -112,6 +128,12 @@ class _SpikingLayer(nn.Module):
         self._layer_index = 0  # set by SNN; decorrelates dropout masks between layers
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def uses_persistent_kernel(self):
+        """True if this layer's time loop runs as ONE persistent launch whose workgroups wait for each other
+        (RLIF / RadLIF up to 1024 hidden units) — what sparch_amd.dp keys its all-reduce policy on."""
+        return self.kind in ("RLIF", "RadLIF") and not Fn.rec_step_path(self.hidden_size)
+
     def _draw_states(self, rows, device):
         """Random initial u, [w], s from torch's global CPU generator, in the reference's
         order (snns.py:286-287, 423-425, 558-559, 700-702), then moved to the device."""
@@ -150,6 +172,7 @@ class _SpikingLayer(nn.Module):
         u0, w0, s0 = self._draw_states(rows, x.device)
         p_drop = float(self.dropout) if self.training else 0.0
         is_bn = self.normalization == "batchnorm"
+        in_scale, in_s16 = _spike_tag(x)
         cfg = {
             "kind": self.kind,
             "normalization": self.normalization if self.normalize else "none",
@@ -161,8 +184,8 @@ class _SpikingLayer(nn.Module):
             "running_mean": self.norm.running_mean if is_bn else None,
             "running_var": self.norm.running_var if is_bn else None,
             # set when x came straight out of one of our spiking layers: entries are 0 or this constant
-            "in_spike_scale": getattr(x, "_sparch_spike_scale", None),
-            "in_spike16": getattr(x, "_sparch_spike16", None),  # the same spikes as a bf16 plane
+            "in_spike_scale": in_scale,
+            "in_spike16": in_s16,  # the same spikes as a bf16 plane
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1
@@ -172,8 +195,8 @@ class _SpikingLayer(nn.Module):
             cfg, x, self.W.weight, self.W.bias, nw, nb, self.alpha,
             getattr(self, "beta", None), getattr(self, "a", None), getattr(self, "b", None),
             self.V.weight if hasattr(self, "V") else None, u0, w0, s0)
-        s._sparch_spike_scale = 1.0 / (1.0 - p_drop)  # lets the next layer take the exact bf16-split GEMMs
-        s._sparch_spike16 = s16                       # ... and read the spikes as a bf16 plane (half the bytes)
+        # lets the next layer take the exact bf16-split GEMMs and read the spikes as a bf16 plane (half the bytes)
+        _tag_spikes(s, 1.0 / (1.0 - p_drop), s16 if s16.numel() else None)
         return s, rate
 
     def forward(self, x):
@@ -249,13 +272,14 @@ class ReadoutLayer(nn.Module):
         Fn._require_device(x, "input")
         u0 = _rand_to(x.shape[0], self.hidden_size, x.device)  # snns.py:812
         is_bn = self.normalization == "batchnorm"
+        in_scale, in_s16 = _spike_tag(x)
         cfg = {
             "normalization": self.normalization if self.normalize else "none",
             "training": bool(self.training),
             "running_mean": self.norm.running_mean if is_bn else None,
             "running_var": self.norm.running_var if is_bn else None,
-            "in_spike_scale": getattr(x, "_sparch_spike_scale", None),
-            "in_spike16": getattr(x, "_sparch_spike16", None),  # the same spikes as a bf16 plane
+            "in_spike_scale": in_scale,
+            "in_spike16": in_s16,  # the same spikes as a bf16 plane
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1

@@ -25,10 +25,12 @@ def pytest_sessionstart(session):
 
 
 def _has_gpu():
+    """device_count() does not initialise the GPU in this process (is_available() would): the first test of a
+    GPU session starts child processes that must come before any GPU use of the parent."""
     try:
         import torch
 
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 

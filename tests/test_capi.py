@@ -50,6 +50,6 @@ def test_host_only_entry_points():
 def test_argument_validation_returns_codes_without_launching():
     lib = _capi.lib
     assert lib.sparch_gemm_nt(0, 4, 4, None, 4, None, 4, None, 4, None, None, None) == -1
-    assert lib.sparch_readout_fwd(2, 3, 65, 1, None, None, 1, 1, 1, None, None) == -1  # C > 64
+    assert lib.sparch_readout_fwd(2, 3, 257, 1, None, None, 1, 1, 1, None, None) == -1  # C > 256
     assert lib.sparch_cell_fwd(2, 1, 1, 1, 4, 16, None, None, 16, None, None, None, 16, None, 16,
                                1.0, 0.0, 0, 16, None, None, None, None, None) == -1  # kind RLIF on non-recurrent entry

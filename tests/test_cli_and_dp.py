@@ -31,7 +31,7 @@ def test_flag_names_and_defaults_match_reference():
     ns = vars(_parser().parse_args([]))
     for k, v in {**REF_MODEL, **REF_TRAIN}.items():
         assert ns[k] == v, k
-    assert set(ns) - set(REF_MODEL) - set(REF_TRAIN) == {"synthetic", "synthetic_batches", "seq_len"}
+    assert set(ns) - set(REF_MODEL) - set(REF_TRAIN) == {"synthetic", "synthetic_batches", "seq_len", "sync_bn"}
 
 
 def test_flag_parsing_booleans_and_choices():
@@ -76,10 +76,16 @@ def _dp_worker(rank, world, port, q, overlap=None):
     net = _Toy()
     if overlap is None:
         red = dp.GradAllReducer(net)
-        assert red.overlap is True  # no recurrent (persistent-kernel) layers -> per-layer overlapped launches
-        net.snn[1].V = torch.nn.Identity()  # a layer with a recurrent matrix switches the default to deferred
+        assert red.overlap is True  # no persistent-kernel layers -> per-layer overlapped launches
+        net.snn[1].V = torch.nn.Identity()  # a recurrent matrix alone (LiGRU / GRU: launch per step) changes nothing
+        assert dp.GradAllReducer(net).overlap is True
+        # a layer on the persistent recurrent kernel: deferred when its grid fills the GPU (or the batch is
+        # unknown), overlapped when the per-rank batch leaves CUs to RCCL
+        net.snn[1].uses_persistent_kernel, net.snn[1].hidden_size = True, 1024
         assert dp.GradAllReducer(net).overlap is False
-        del net.snn[1].V
+        assert dp.GradAllReducer(net, rows_per_rank=256).overlap is False
+        assert dp.GradAllReducer(net, rows_per_rank=128).overlap is True
+        del net.snn[1].V, net.snn[1].uses_persistent_kernel, net.snn[1].hidden_size
     else:
         red = dp.GradAllReducer(net, overlap=overlap)
     assert len(red.buckets) == 3 and red.bytes_per_step == sum(p.numel() for p in net.parameters()) * 4
@@ -101,12 +107,12 @@ def _dp_worker(rank, world, port, q, overlap=None):
 @pytest.mark.parametrize("overlap", [None, False])
 def test_grad_allreducer_gloo_world2(overlap):
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = 29600 + (os.getpid() % 200) + (7 if overlap is False else 0)
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get()
+    got = q.get(timeout=180)  # a rank that died must fail the test, not hang it
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

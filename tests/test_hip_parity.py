@@ -687,6 +687,31 @@ def test_snn_long_sequence_non_finite_gradient_mask_matches_reference(sp, monkey
     assert n_bad > 0
 
 
+def test_inplace_edit_between_layers_invalidates_the_spike_fast_path(sp):
+    """the spike fast path (bf16 plane + scale handed from layer to layer) is keyed on the tensor's
+    version counter: after an in-place edit of a layer's output the next layer must treat it as an ordinary
+    real-valued input, not read the stale plane."""
+    cfg, x, y, params, init, z = snn_case("snn_adLIF_bn")
+    net = _build(sp, cfg, params).eval()
+    from sparch_amd import snns as snn_mod
+    with torch.no_grad():
+        torch.manual_seed(1)
+        s0, _ = net.snn[0].forward_with_rate(x.to(DEV))
+        assert snn_mod._spike_tag(s0)[0] == 1.0 and snn_mod._spike_tag(s0)[1] is not None
+        s0.mul_(0.5)
+        s0[:, ::2, :] = 0.25
+        assert snn_mod._spike_tag(s0) == (None, None)
+        torch.manual_seed(2)
+        s1, _ = net.snn[1].forward_with_rate(s0)
+        # oracle: layer 1 on the edited tensor
+        torch.manual_seed(2)
+        st = {"u0": torch.rand(cfg["B"], cfg["layer_sizes"][1]), "w0": torch.rand(cfg["B"], cfg["layer_sizes"][1]),
+              "s0": torch.rand(cfg["B"], cfg["layer_sizes"][1])}
+        ref = orc.hidden_layer("adLIF", s0.cpu(), params, "snn.1.", st, normalization="batchnorm", training=False)
+    assert float((s1.cpu() != ref).float().mean()) <= 2e-3
+    assert float(ref.sum()) > 0
+
+
 def test_eval_mode_batchnorm_gradients_vs_oracle(sp):
     """net.eval() with autograd on (fixed running statistics): gradients of a non-recurrent net must match
     the oracle's autograd through F.batch_norm(training=False)."""
@@ -923,7 +948,9 @@ def test_adam_step_matches_torch_adam():
     from sparch_amd.optim import Adam
 
     g = torch.Generator().manual_seed(5)
-    shapes = [(1024, 700), (1024,), (35, 1024), (3,), (1,), (4097,)] + [(17, 5)] * 24
+    # > 24 tensors per launch with EMPTY ones among them (they are skipped inside a batch: ADVICE r1, each
+    # tensor must still be stepped exactly once)
+    shapes = [(1024, 700), (1024,), (0,), (35, 1024), (3,), (1,), (4097,)] + [(17, 5)] * 12 + [(0, 4)] + [(17, 5)] * 14
     p_cpu = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
     p_gpu = [p.detach().clone().cuda().requires_grad_(True) for p in p_cpu]
     o_cpu = torch.optim.Adam(p_cpu, lr=1e-2)
@@ -947,6 +974,18 @@ def test_adam_step_matches_torch_adam():
     assert float(o_new.state_dict()["state"][0]["step"]) == 6.0
     with pytest.raises(NotImplementedError):
         Adam(p_gpu, amsgrad=True)
+    # the step is guarded by the recurrent kernels' status word: raised -> parameters and moments untouched
+    from sparch_amd import functional as Fn
+    before = [p.detach().clone() for p in p_gpu]
+    Fn.status_word("cuda")[0] = 1
+    try:
+        o_gpu.step()
+        torch.cuda.synchronize()
+    finally:
+        Fn.status_word("cuda").zero_()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, p_gpu))
+    o_gpu.step()
+    assert not torch.equal(before[0], p_gpu[0].detach())
 
 
 # ------------------------------------------------------------------ f-4: non-spiking baselines (anns.py)

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""One rank of the two-rank data-parallel check on ONE GPU (tests/test_a_multirank_gpu.py starts two of these
+before anything in the test session touches the GPU).  Rendezvous over gloo on 127.0.0.1, every rank on cuda:0
+(SPARCH_SHARE_GPU=1).  Each rank
+  1. runs a real RadLIF training step on its half of a global batch through sparch_amd.dp.GradAllReducer (both
+     launch policies), and checks the averaged gradients against the mean of the two shards' gradients that it
+     computes alone (same kernels, same seeded initial states -> equal up to the order of the final sum);
+  2. with SyncBN (functional.SYNC_BN) runs an adLIF net on its half and checks that its output rows, the
+     running statistics and the reduced gradients match ONE process running the whole batch.
+Exit code 0 = all checks passed on this rank."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sparch_amd  # noqa: E402
+from sparch_amd import dp  # noqa: E402
+from sparch_amd import functional as Fn  # noqa: E402
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-6))
+
+
+def grads_of(net, x, y, seed, reducer=None):
+    net.zero_grad(set_to_none=True)
+    for lay in net.snn:
+        lay._calls = 0
+    torch.manual_seed(seed)  # the layers draw their initial states from the CPU generator
+    out, rates = net(x)
+    torch.nn.functional.cross_entropy(out, y).backward()
+    if reducer is not None:
+        reducer.finish()
+    Fn.check_status()
+    return out.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()}
+
+
+def main():
+    rank, world, _ = dp.init_from_env()
+    assert world == 2 and dist.get_backend() == "gloo"
+    dev = torch.device("cuda", 0)
+    B, T, C = 16, 30, 40
+    g = torch.Generator().manual_seed(11)
+    x_all = (torch.rand(B, T, C, generator=g) < 0.2).float().to(dev)
+    y_all = torch.randint(0, 20, (B,), generator=g).to(dev)
+    xs, ys = dp.shard_batch(x_all, rank, world), dp.shard_batch(y_all, rank, world)
+
+    # ---- 1. gradient all-reduce on a recurrent model, both policies
+    torch.manual_seed(1)
+    net = sparch_amd.SNN((B // world, None, C), [64, 64, 20], neuron_type="RadLIF", dropout=0.0).to(dev).train()
+    for p in net.parameters():
+        dist.broadcast(p.data, src=0)
+    assert net.snn[0].uses_persistent_kernel
+    shard = []
+    for r in range(world):  # what each shard contributes, computed alone (running stats restored afterwards)
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        shard.append(grads_of(net, dp.shard_batch(x_all, r, world), dp.shard_batch(y_all, r, world), 100 + r)[1])
+        net.load_state_dict(state)
+    for overlap in (False, True):
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        red = dp.GradAllReducer(net, overlap=overlap, rows_per_rank=B // world)
+        _, got = grads_of(net, xs, ys, 100 + rank, red)
+        red.remove()
+        net.load_state_dict(state)
+        for k in got:
+            ref = (shard[0][k] + shard[1][k]) / 2
+            e = relmax(got[k], ref)
+            assert e <= 1e-6, (overlap, k, e)
+    # default policy: this small batch leaves CUs free -> overlapped; a batch that fills the GPU -> deferred
+    assert dp.GradAllReducer(net, rows_per_rank=B // world).overlap is True
+    big = sparch_amd.SNN((256, None, C), [1024, 1024, 20], neuron_type="RadLIF")
+    assert dp.GradAllReducer(big, rows_per_rank=256).overlap is False
+    assert dp.GradAllReducer(big, rows_per_rank=64).overlap is True
+
+    # ---- 2. SyncBN: two ranks x B/2 rows == one process x B rows
+    torch.manual_seed(2)
+    net = sparch_amd.SNN((B, None, C), [48, 48, 20], neuron_type="adLIF", dropout=0.0).to(dev).train()
+    for p in net.parameters():
+        dist.broadcast(p.data, src=0)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def states_for(rows):  # identical initial states for the same global rows in both runs
+        gen = torch.Generator().manual_seed(5)
+        full = [torch.rand(B, 48, generator=gen) for _ in range(6)] + [torch.rand(B, 20, generator=gen)]
+        return iter([t[rows].contiguous() for t in full])
+
+    from sparch_amd import snns as snn_mod
+    real_rand = snn_mod._rand_to
+
+    def run(x, y, rows, sync):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        it = states_for(rows)
+        snn_mod._rand_to = lambda r, c, device: next(it).to(device)
+        Fn.SYNC_BN = {"group": None, "world": world} if sync else None
+        try:
+            out, rates = net(x)
+            (torch.nn.functional.cross_entropy(out, y, reduction="sum") / B).backward()
+        finally:
+            snn_mod._rand_to = real_rand
+            Fn.SYNC_BN = None
+        Fn.check_status()
+        return (out.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()},
+                {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+
+    rows = slice(rank * B // world, (rank + 1) * B // world)
+    out_full, g_full, st_full = run(x_all, y_all, slice(0, B), False)
+    out_dp, g_dp, st_dp = run(xs, ys, rows, True)
+    flat = torch.cat([v.reshape(-1) for v in g_dp.values()])
+    dist.all_reduce(flat)  # loss is normalised by the GLOBAL batch above: the shards' gradients add up
+    off = 0
+    # the batch statistics agree up to summation order, so a membrane potential within rounding of the
+    # threshold may flip: allow a handful of differing output entries, none expected
+    assert float((out_dp - out_full[rows]).abs().max()) <= 2e-3 * T
+    for k, v in st_dp.items():
+        np.testing.assert_allclose(v.cpu().numpy(), st_full[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    for k, v in g_dp.items():
+        n = v.numel()
+        e = relmax(flat[off:off + n].view_as(v), g_full[k])
+        off += n
+        assert e <= 5e-3, (k, e)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: data-parallel checks passed", flush=True)
+
+
+if __name__ == "__main__":
+    main()
