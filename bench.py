@@ -9,8 +9,13 @@ SSC-shaped input (B=256 per GPU, T=250, C=700), fp32, at 1/2/4/8 MI355X.
 A step = one pass of the training hot path over one resident synthetic batch:
 zero_grad -> SNN.forward -> cross-entropy on the softmax-sum -> backward (-> per-layer RCCL
 gradient all-reduce, overlapped) -> Adam.step   (reference: exp.py:359-377).
-Inputs are in HBM before the timed region.  N>1 is weak scaling: every rank runs the full
-B=256 batch (data parallel, no data-path collective; only the gradient all-reduce).
+Inputs are in HBM before the timed region.  N>1 defaults to weak scaling: every rank runs the full
+B=256 batch (data parallel, no data-path collective; only the gradient all-reduce); `--scaling strong`
+keeps the GLOBAL batch at B and gives every rank B/N rows (SURVEY.md §8e asks for both curves).
+
+Other workloads (`--workload`): cfg2 / cfg4 / cfg5 are BASELINE.json configs[1] / [3] / [4] (cfg4 feeds raw
+audio through the HIP mel filterbank inside the step), rnn / mlp / ligru / gru the reference's non-spiking
+baselines at the headline shape (SURVEY f-4).  The driver's default line is cfg3.
 
 Rank 0 prints ONE JSON line with the contract keys plus
   "roofline":     dominant kernel's achieved algorithmic rate vs the gfx950 peak (HIP events, live)
@@ -43,7 +48,15 @@ WORKLOADS = {
     "mlp": dict(neuron_type="MLP", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
     "ligru": dict(neuron_type="LiGRU", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
     "gru": dict(neuron_type="GRU", layer_sizes=[1024, 1024, 35], B=256, T=250, C=700, pdrop=0.1),
+    # BASELINE.json configs[3]: RadLIF 3x1024 on SC raw audio -> HIP mel filterbank front-end (1 s clips at
+    # 16 kHz -> 98 frames x 40 log-mel bins) -> the network; the front-end runs inside the timed step
+    "cfg4": dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 35], B=256, T=98, C=40, pdrop=0.1, audio=16000),
+    # BASELINE.json configs[4]: bidirectional RadLIF 4x1024, T=1000 long-sequence stress (fp32 here, >= bf16)
+    "cfg5": dict(neuron_type="RadLIF", layer_sizes=[1024, 1024, 1024, 35], B=256, T=1000, C=700, pdrop=0.1,
+                 bidirectional=True),
 }
+CONFIG_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}  # position in BASELINE.json "configs"
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the pipe the split products run on)
 WORKLOAD = WORKLOADS["cfg3"]
 
 
@@ -56,17 +69,32 @@ def algorithmic_work(name, B, T, H):
     if name.startswith("rec_cell_fwd") or name.startswith("rec_cell_bwd") or name.startswith("ann_rec_"):
         # one (B x H) x (H x H) recurrent product per time step (s_{t-1} V  or  dWx_{t+1} V^T)
         return "mfma", 2.0 * B * H * H * T, "flop"
+    if name.startswith("fbank"):
+        return "hbm", None, "byte"
     if name.startswith("cell_fwd") or name.startswith("cell_bwd"):
         per = 16 if "adLIF" in name else 12  # bytes per neuron-step: Wx + s + u (+ w) | g + u (+ w) + dWx
         return "hbm", float(per) * B * T * H, "byte"
     return None
 
 
+def bf16_issue_factor(name):
+    """bf16 MFMA products issued per algorithmic fp32 product by the exact-split kernels: spike x dense = 3
+    planes, dense x dense = 6 cross terms."""
+    if name.startswith("rec_cell_fwd") or name.startswith("gemm_spike"):
+        return 3.0
+    if name.startswith("rec_cell_bwd") or name.startswith("ann_rec_") or name.startswith("gemm_nn") \
+            or name.startswith("gemm_tn") or name.startswith("gemm_nt"):
+        return 6.0
+    return None  # gemm_auto_*: decided on the device (3 for bf16-exact inputs, else 6)
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950
     FETCH_SIZE correction applied).  bench.py cannot run the profiler on itself; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -80,8 +108,25 @@ def pmc_traffic(kernel_label):
     return None
 
 
-def cpu_baseline(rank):
-    """The oracle on the host cores, bounded sample of the same workload (same model, B=64 of 256)."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state_dict, x_cpu, y_cpu):
+    """the oracle (eager PyTorch restatement of the reference's path, pinned to the reference by
+    tests/golden) on this host's cores, in the same run: the GPU model's own initial parameters, the first
+    B=64 rows of the GPU batch, one warm-up and the median of three timed forward+backward passes in the
+    default denormal mode (the reference never sets flush-to-zero), plus one pass with flush-to-zero as a
+    footnote.  pdrop = 0 (dropout masks cannot match across devices; the mask multiply is negligible here)."""
+    import statistics
+
     from oracle import snn_oracle as orc
 
     try:
@@ -92,41 +137,35 @@ def cpu_baseline(rank):
     torch.set_num_threads(n_threads)
     Bs, T, C = 64, WORKLOAD["T"], WORKLOAD["C"]
     sizes = WORKLOAD["layer_sizes"]
-    g = torch.Generator().manual_seed(1234)
-    H = sizes[0]
-    p = {}
-    fan = C
-    for i in range(2):
-        p[f"snn.{i}.W.weight"] = (torch.rand(H, fan, generator=g) * 2 - 1) / fan ** 0.5
-        p[f"snn.{i}.V.weight"] = torch.nn.init.orthogonal_(torch.empty(H, H), generator=g)
-        p[f"snn.{i}.alpha"] = torch.rand(H, generator=g) * 0.14 + 0.82
-        p[f"snn.{i}.beta"] = torch.rand(H, generator=g) * 0.024 + 0.967
-        p[f"snn.{i}.a"] = torch.rand(H, generator=g) * 2 - 1
-        p[f"snn.{i}.b"] = torch.rand(H, generator=g) * 2
-        p[f"snn.{i}.norm.weight"], p[f"snn.{i}.norm.bias"] = torch.ones(H), torch.zeros(H)
-        p[f"snn.{i}.norm.running_mean"], p[f"snn.{i}.norm.running_var"] = torch.zeros(H), torch.ones(H)
-        fan = H
-    Co = sizes[-1]
-    p["snn.2.W.weight"] = (torch.rand(Co, H, generator=g) * 2 - 1) / H ** 0.5
-    p["snn.2.alpha"] = torch.rand(Co, generator=g) * 0.14 + 0.82
-    p["snn.2.norm.weight"], p["snn.2.norm.bias"] = torch.ones(Co), torch.zeros(Co)
-    p["snn.2.norm.running_mean"], p["snn.2.norm.running_var"] = torch.zeros(Co), torch.ones(Co)
+    x, y = x_cpu[:Bs].contiguous(), y_cpu[:Bs].contiguous()
+    p = {k: v.detach().cpu().clone() for k, v in state_dict.items()}
     for k, v in p.items():
-        if "running" not in k:
+        if v.dtype == torch.float32 and "running" not in k:
             v.requires_grad_(True)
-    x = (torch.rand(Bs, T, C, generator=g) < 0.05).float()
-    y = torch.randint(0, Co, (Bs,), generator=g)
-    torch.manual_seed(7)
-    init = orc.draw_init_states(Bs, sizes, "RadLIF")
-    t0 = time.perf_counter()
-    out, rates = orc.snn_forward(x, p, neuron_type="RadLIF", num_layers=3, init_states=init, training=True,
-                                 stats={})
-    loss = orc.train_step_loss(out, rates, y)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": Bs * T / dt, "unit": "timesteps*samples/s", "cores": n_threads, "kind": "port",
-            "sample": f"1 fwd+bwd of the same RadLIF [1024,1024,35] model at B={Bs} (of 256), T={T}, C={C}, "
-                      f"pdrop=0, eager torch CPU oracle, {dt:.1f} s"}
+
+    def one():
+        for v in p.values():
+            v.grad = None
+        torch.manual_seed(7)
+        init = orc.draw_init_states(Bs, sizes, "RadLIF")
+        t0 = time.perf_counter()
+        out, rates = orc.snn_forward(x, p, neuron_type="RadLIF", num_layers=len(sizes), init_states=init,
+                                     training=True, stats={})
+        orc.train_step_loss(out, rates, y).backward()
+        return time.perf_counter() - t0
+
+    one()  # warm-up
+    times = [one() for _ in range(3)]
+    med = statistics.median(times)
+    torch.set_flush_denormal(True)
+    ftz = one()
+    torch.set_flush_denormal(False)
+    return {"value": Bs * T / med, "unit": "timesteps*samples/s", "cores": n_threads, "kind": "port",
+            "cpu_model": _cpu_model(), "value_flush_denormals": Bs * T / ftz,
+            "sample": f"fwd+bwd of the same RadLIF {sizes} model (the GPU run's initial parameters) on rows 0..{Bs - 1} "
+                      f"of the GPU batch (B={Bs} of {WORKLOAD['B']}), T={T}, C={C}, pdrop=0, eager torch CPU oracle: "
+                      f"1 warm-up, median of 3 = {med:.1f} s ({', '.join(f'{t:.1f}' for t in times)}); "
+                      f"with flush-to-zero {ftz:.1f} s (footnote; the reference runs with denormals on)"}
 
 
 def main():
@@ -136,6 +175,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = the workload's batch per GPU, strong = that batch split over the GPUs")
+    ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm over the global batch")
     args = ap.parse_args()
     global WORKLOAD
     WORKLOAD = WORKLOADS[args.workload]
@@ -160,6 +202,11 @@ def main():
 
     w = WORKLOAD
     B, T, C, H = w["B"], w["T"], w["C"], w["layer_sizes"][0]
+    bidir = bool(w.get("bidirectional", False))
+    if args.scaling == "strong":
+        if B % world != 0:
+            raise SystemExit(f"--scaling strong: global batch {B} is not divisible by {world} GPUs")
+        B = B // world  # rows of the global batch on this rank
     torch.manual_seed(1234)
     if w["neuron_type"] in ("RNN", "MLP", "LiGRU", "GRU"):
         from sparch_amd.anns import ANN
@@ -167,19 +214,29 @@ def main():
                   normalization="batchnorm").to(dev)
     else:
         net = sparch_amd.SNN((B, None, C), w["layer_sizes"], neuron_type=w["neuron_type"], dropout=w["pdrop"],
-                             normalization="batchnorm").to(dev)
+                             normalization="batchnorm", bidirectional=bidir).to(dev)
     net.train()
+    state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}  # for the CPU baseline leg
     opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)  # exp.py:89 (same arithmetic, one launch: SURVEY f-2)
     loss_fn = torch.nn.CrossEntropyLoss()           # exp.py:100
-    reducer = dp.GradAllReducer(net) if world > 1 else None
+    reducer = dp.GradAllReducer(net, rows_per_rank=B) if world > 1 else None
+    if world > 1 and args.sync_bn:
+        Fn.SYNC_BN = {"group": None, "world": world}
     g = torch.Generator().manual_seed(4321 + rank)
-    x = (torch.rand(B, T, C, generator=g) < 0.05).float().to(dev)
-    y = torch.randint(0, w["layer_sizes"][-1], (B,), generator=g).to(dev)
+    audio = w.get("audio")
+    if audio:  # uniform noise in [-0.1, 0.1] + a 440 Hz tone, 1 s at 16 kHz
+        tt = torch.arange(audio) / 16000.0
+        x_cpu = 0.1 * (torch.rand(B, audio, generator=g) * 2 - 1) + 0.3 * torch.sin(2 * torch.pi * 440.0 * tt)[None]
+    else:
+        x_cpu = (torch.rand(B, T, C, generator=g) < 0.05).float()
+    y_cpu = torch.randint(0, w["layer_sizes"][-1], (B,), generator=g)
+    x, y = x_cpu.to(dev), y_cpu.to(dev)
     torch.manual_seed(99 + rank)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out, rates = net(x)
+        feats = Fn.fbank(x, num_mel_bins=C) if audio else x  # nonspiking_datasets.py:96 on the device
+        out, rates = net(feats)
         loss = loss_fn(out, y)
         loss.backward()
         if reducer is not None:
@@ -218,7 +275,9 @@ def main():
         kern = {k: {"launches": c, "avg_ms": t / c} for k, (c, t) in totals.items()}
         dom = max(totals.items(), key=lambda kv: kv[1][1])[0] if totals else None
         roof = None
-        work = algorithmic_work(dom, B, T, H) if dom is not None else None
+        work = algorithmic_work(dom, B * (2 if bidir else 1), T, H) if dom is not None else None
+        if work is not None and work[1] is None:
+            work = None
         if work is not None:
             bound, amount, _ = work
             avg_s = kern[dom]["avg_ms"] * 1e-3
@@ -227,6 +286,10 @@ def main():
                 roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(dom),
                         "avg_ms": kern[dom]["avg_ms"]}
+                k6 = bf16_issue_factor(dom)
+                if k6 is not None:  # the same time priced as what the kernel really issues: bf16 MFMAs of the
+                    roof["frac_bf16_pipe"] = ach * k6 / PEAK_MFMA_BF16_TFLOPS  # exact split, vs the bf16 peak
+                    roof["bf16_products_per_fp32_product"] = k6
             else:
                 ach = amount / avg_s / 1e9
                 roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -235,23 +298,37 @@ def main():
               f"timing the CPU oracle sample next", file=sys.stderr, flush=True)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
-            cpu = cpu_baseline(rank)
+            cpu = cpu_baseline(state0, x_cpu, y_cpu)
+        titles = {"cfg3": "RadLIF 3x1024 SSC shape", "cfg2": "adLIF 3x512 SHD shape",
+                  "cfg4": "RadLIF 3x1024 on SC raw audio through the HIP mel front-end",
+                  "cfg5": "bidirectional RadLIF 4x1024 T=1000",
+                  "rnn": "RNN baseline 3x1024 SSC shape", "mlp": "MLP baseline 3x1024 SSC shape",
+                  "ligru": "LiGRU baseline 3x1024 SSC shape", "gru": "GRU baseline 3x1024 SSC shape"}
+        origin = (f"BASELINE.json configs[{CONFIG_INDEX[args.workload]}]" if args.workload in CONFIG_INDEX else
+                  "SURVEY.md f-4: the reference's non-spiking baseline at the configs[2] shape")
+        inp = (f"{audio}-sample waveforms (noise + 440 Hz tone) -> sparch_fbank_fwd -> T={T} C={C}" if audio else
+               f"T={T} C={C} Bernoulli(0.05) spikes")
+        note = None
+        if args.workload == "ligru" and final_loss != final_loss:
+            note = ("final_loss is NaN as in the reference: the real reference LiGRU (unbounded ReLU candidate, "
+                    "lr 1e-2) is NaN after one Adam step at this shape too (checked in round 1)")
         line = {
-            "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " +
-                      {"cfg3": "RadLIF 3x1024 SSC shape", "cfg2": "adLIF 3x512 SHD shape",
-                       "rnn": "RNN baseline 3x1024 SSC shape", "mlp": "MLP baseline 3x1024 SSC shape",
-                       "ligru": "LiGRU baseline 3x1024 SSC shape", "gru": "GRU baseline 3x1024 SSC shape"}[args.workload],
+            "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " + titles[args.workload],
             "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w['neuron_type']} {w['layer_sizes']} batchnorm pdrop={w['pdrop']}, B={B}/GPU "
-                                   f"T={T} C={C} Bernoulli(0.05) spikes (BASELINE.json "
-                                   f"configs[{2 if args.workload == 'cfg3' else 1}])",
-                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+            "config": {"workload": f"{'bidirectional ' if bidir else ''}{w['neuron_type']} {w['layer_sizes']} batchnorm "
+                                   f"pdrop={w['pdrop']}, B={B}/GPU {inp} ({origin})",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
+                       "sync_bn": bool(world > 1 and args.sync_bn),
+                       "grad_allreduce": (None if reducer is None else
+                                          ("overlapped with backward" if reducer.overlap else "one collective after backward"))},
             "roofline": roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["avg_ms"] * v["launches"] / args.steps, 4) for k, v in kern.items()},
             "final_loss": final_loss,
         }
+        if note:
+            line["note"] = note
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -705,8 +705,10 @@ def fbank(wave, num_mel_bins=40):
     n_clips, n_samples = wave.shape
     frames = lib.sparch_fbank_frames(n_samples)
     out = torch.empty(n_clips, frames, num_mel_bins, dtype=torch.float32, device=wave.device)
+    tok = timer.start(f"fbank[{n_clips}x{n_samples}]")
     check(lib.sparch_fbank_fwd(n_clips, n_samples, num_mel_bins, ptr(wave), ptr(out), _stream()),
           "sparch_fbank_fwd")
+    timer.stop(tok)
     return out
 
 
