@@ -22,8 +22,19 @@ __device__ __forceinline__ double col_sum64(const float* __restrict__ base, int 
                                             double (*red)[CS_COLS]) {
     const int c = threadIdx.x & (CS_COLS - 1), q = threadIdx.x / CS_COLS;
     double s = 0.0;
-    if (ok)
-        for (int r = q; r < n; r += CS_LANES) s += (double)base[(size_t)r * ld + col];
+    if (ok) {
+        // eight independent loads in flight per thread (a one-load-per-iteration loop is a chain of ~1 us
+        // memory round trips: 25 us for 500 partial rows), summed in a fixed order
+        int r = q;
+        for (; r + 7 * CS_LANES < n; r += 8 * CS_LANES) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = base[(size_t)(r + j * CS_LANES) * ld + col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; r < n; r += CS_LANES) s += (double)base[(size_t)r * ld + col];
+    }
     red[q][c] = s;
     __syncthreads();
     double tot = 0.0;

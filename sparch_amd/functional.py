@@ -531,6 +531,7 @@ class SpikingLayerFn(torch.autograd.Function):
         ctx.shape = (B, T, K, H)
         ctx.nsaved = nsaved
         ctx.cell_saved = saved
+        ctx.set_materialize_grads(False)  # no zero tensors for unused outputs (s16 is as large as s in bf16)
         ctx.save_for_backward(x2, W, nw, alpha, beta, a, b, V, u0, w0, s0,
                               Wx_raw if norm in ("batchnorm", "layernorm") else None)
         if s16 is None:  # keep the output arity fixed

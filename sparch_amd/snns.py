@@ -161,15 +161,16 @@ class _SpikingLayer(nn.Module):
         return p
 
     # ------------------------------------------------------------------ forward
-    def forward_with_rate(self, x):
+    def forward_with_rate(self, x, states=None):
         """Returns (spikes (B,T,H*(1+bidir)), firing_rate (H*(1+bidir),)).  Equivalent to the
-        reference forward (e.g. snns.py:663-694) followed by `.mean(dim=(0,1))` (174)."""
+        reference forward (e.g. snns.py:663-694) followed by `.mean(dim=(0,1))` (174).
+        states: (u0, w0, s0) drawn ahead of time by SNN.forward (same generator, same order)."""
         Fn._require_device(x, "input")
         dirs = 2 if self.bidirectional else 1
         rows = x.shape[0] * dirs
         if self.batch_size != rows:
             self.batch_size = rows
-        u0, w0, s0 = self._draw_states(rows, x.device)
+        u0, w0, s0 = states if states is not None else self._draw_states(rows, x.device)
         p_drop = float(self.dropout) if self.training else 0.0
         is_bn = self.normalization == "batchnorm"
         in_scale, in_s16 = _spike_tag(x)
@@ -268,9 +269,10 @@ class ReadoutLayer(nn.Module):
             self.norm = norm
         self.drop = nn.Dropout(p=dropout)
 
-    def forward(self, x):
+    def forward(self, x, u0=None):
         Fn._require_device(x, "input")
-        u0 = _rand_to(x.shape[0], self.hidden_size, x.device)  # snns.py:812
+        if u0 is None:
+            u0 = _rand_to(x.shape[0], self.hidden_size, x.device)  # snns.py:812
         is_bn = self.normalization == "batchnorm"
         in_scale, in_s16 = _spike_tag(x)
         cfg = {
@@ -350,13 +352,25 @@ class SNN(nn.Module):
                 x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
             else:
                 raise NotImplementedError
-        rates = []
+        Fn._require_device(x, "input")
+        # All initial states of this forward are drawn NOW, in the reference's order (layer by layer u, [w], s,
+        # then the readout's u: snns.py:286-287 ... 812) from the same CPU generator, so the stream is the one
+        # the reference consumes — but the host does its ~MBs of torch.rand while the GPU is still busy with
+        # the previous step, instead of stalling the queue between two layers (120 us bubbles per layer in
+        # the round-2 kernel trace).
         last = self.num_layers - 1
+        states = []
         for i, layer in enumerate(self.snn):
             if self.use_readout_layer and i == last:
-                x = layer(x)
+                states.append(_rand_to(x.shape[0], layer.hidden_size, x.device))
             else:
-                x, r = layer.forward_with_rate(x)
+                states.append(layer._draw_states(x.shape[0] * (2 if layer.bidirectional else 1), x.device))
+        rates = []
+        for i, layer in enumerate(self.snn):
+            if self.use_readout_layer and i == last:
+                x = layer(x, u0=states[i])
+            else:
+                x, r = layer.forward_with_rate(x, states=states[i])
                 rates.append(r)
         firing_rates = torch.cat(rates) if len(rates) > 1 else rates[0]
         return x, firing_rates
