@@ -204,12 +204,17 @@ int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
  * firing rates (NULL = none).  dWx (Bp,T,H): gradient w.r.t. the normalised projection,
  * virtual-row order but ORIGINAL time index (so rows b and b+B add elementwise).
  * dparam_ws: (4,Bp,H) per-row partials of (dalpha,dbeta,da,db); finish with
- * sparch_colsum_clamped().                                                           */
+ * sparch_colsum_clamped().
+ * BatchNorm backward folded in (SURVEY §8 b2 `bn_dsum` / `bn_dxhat`): with bn_x = the raw projection
+ * (B,T,H), bn_mean / bn_invstd (H) non-NULL the kernel also leaves sum_t dWx and sum_t dWx*xhat,
+ * xhat = (x - mean)*invstd, per (row, column) in planes 4 and 5 of dparam_ws ((6,Bp,H) then): their
+ * column sums are BatchNorm's dbeta / dgamma — no separate pass over dy and x.            */
 int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
                     const float* g_rate, const float* u_save, const float* w_save,
                     const float* alpha, const float* beta, const float* a, const float* b,
                     const float* u0, const float* w0, const float* s0, float theta,
-                    float p_drop, uint64_t seed, float* dWx, float* dparam_ws, void* stream);
+                    float p_drop, uint64_t seed, float* dWx, float* dparam_ws, const float* bn_x,
+                    const float* bn_mean, const float* bn_invstd, void* stream);
 
 /* Recurrent kinds (RLIF, RadLIF).  V (H,H) = V.weight; the diagonal is masked inside
  * (snns.py:566/712).  The recurrent product s_{t-1}*V runs on MFMA with the V slice of
@@ -239,13 +244,16 @@ int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx
 /* Backward: each step's 32x32 dWx tile is handed to the other workgroups through `chan`.
  * s_prev16 (Bp,T,H) receives s_{t-1} as a bf16 plane (binary for t >= 1, a zero row at
  * t = 0: the non-binary s0 term is added by the caller) for dV = s_prev^T * dWx
- * (sparch_gemm_spike16_tn, spike_side 0).                                             */
+ * (sparch_gemm_spike16_tn, spike_side 0).  dparam_ws: (6,Bp,H) = per-row partials of
+ * (dalpha,dbeta,da,db) + the du / dw carries of chunked launches; with bn_x / bn_mean / bn_invstd
+ * non-NULL (see sparch_cell_bwd) planes 6 and 7 receive BatchNorm's sums ((8,Bp,H) then).   */
 int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
                         const float* g_rate, const float* u_save, const float* w_save,
                         const float* alpha, const float* beta, const float* a,
                         const float* b, const float* vpack_t, const float* u0,
                         const float* w0, const float* s0, float theta, float p_drop,
                         uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
+                        const float* bn_x, const float* bn_mean, const float* bn_invstd,
                         void* chan, size_t chan_bytes, uint32_t* status,
                         int steps_per_launch, void* stream);
 /* ONE time step t of the same cells with the recurrent product supplied by the caller — the path for hidden
@@ -269,7 +277,8 @@ int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H, int t, con
                              const float* alpha, const float* beta, const float* a, const float* b,
                              const float* rec, const float* u0, const float* w0, const float* s0,
                              float theta, float p_drop, uint64_t seed, float* dWx,
-                             uint16_t* s_prev16, float* dparam_ws, float* dwx_step, void* stream);
+                             uint16_t* s_prev16, float* dparam_ws, const float* bn_x,
+                             const float* bn_mean, const float* bn_invstd, float* dwx_step, void* stream);
 
 /* Finish per-row partials: out[j][h] = sum_r ws[j][r][h], zeroed where the raw parameter
  * lies outside [lo_j, hi_j] (torch.clamp's gradient gate).  n_params <= 4; raw[j]/lim may
@@ -288,13 +297,15 @@ int sparch_colsum(int M, int H, const float* x, float* out, void* ws, size_t ws_
 /* ------------------------------------------------------------------------------------
  * G5  readout cell  (replaces _readout_cell, snns.py:808-825, and its autograd replay):
  *     u_t = alpha*u + (1-alpha)*(Wx_t*scale+shift);  out += softmax(u_t).
- *     One wave per batch row, classes on lanes (C <= 64).
+ *     One workgroup per batch row, classes on threads (C <= 256).
+ *     Backward: dalpha_ws (1,B,C) per-row partials of dalpha; with bn_x (B,T,C) / bn_mean / bn_invstd
+ *     non-NULL also sum_t dWx and sum_t dWx*xhat in planes 1 and 2 ((3,B,C) then), see sparch_cell_bwd.
  * ---------------------------------------------------------------------------------- */
 int sparch_readout_fwd(int B, int T, int C, const float* Wx, const float* scale,
                        const float* shift, const float* alpha, const float* u0, float* out,
                        float* u_save, void* stream);
-int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* Wx,
-                       const float* scale, const float* shift, const float* u_save,
+int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* bn_x,
+                       const float* bn_mean, const float* bn_invstd, const float* u_save,
                        const float* alpha, const float* u0, float* dWx, float* dalpha_ws,
                        void* stream);
 

@@ -62,7 +62,7 @@ PROTOTYPES = {
     "sparch_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P,
                                 c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
-                                c_float, c_float, c_uint64, P, P, P]),
+                                c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_vpack_bytes": (c_size_t, [c_int]),
     "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
     "sparch_vmask": (c_int, [c_int, P, P, P]),
@@ -70,11 +70,11 @@ PROTOTYPES = {
     "sparch_rec_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                                     c_float, c_float, c_uint64, P, P, P, P, P, P, c_size_t, P, c_int, P]),
     "sparch_rec_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
-                                    c_float, c_float, c_uint64, P, P, P, P, c_size_t, P, c_int, P]),
+                                    c_float, c_float, c_uint64, P, P, P, P, P, P, P, c_size_t, P, c_int, P]),
     "sparch_rec_cell_step_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
                                          c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
     "sparch_rec_cell_step_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
-                                         P, c_float, c_float, c_uint64, P, P, P, P, P]),
+                                         P, c_float, c_float, c_uint64, P, P, P, P, P, P, P, P]),
     "sparch_colsum_clamped": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "sparch_add_halves": (c_int, [c_size_t, P, P, P]),
     "sparch_colsum": (c_int, [c_int, c_int, P, P, P, c_size_t, P]),

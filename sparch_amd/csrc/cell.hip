@@ -33,6 +33,9 @@ struct CellArgs {
     // backward
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; float* dparam_ws;
+    // BatchNorm backward folded in (nullable): the raw projection and its per-column statistics; the kernel
+    // then also leaves sum_t dWx and sum_t dWx*xhat per (row, column) in two more planes of dparam_ws
+    const float* bn_x; const float* bn_mean; const float* bn_invstd;
 };
 
 template <int VEC>
@@ -149,8 +152,13 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
     float al[VEC], oma[VEC], be[VEC], pa[VEC], pb[VEC], gr[VEC];
     float du_n[VEC], dw_n[VEC], u_t[VEC];
     float acc_al[VEC], acc_be[VEC], acc_a[VEC], acc_b[VEC];
+    const bool bn = c.bn_x != nullptr;
+    float bn_mu[VEC], bn_is[VEC], acc_dy[VEC], acc_dyx[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
+        bn_mu[e] = bn ? c.bn_mean[h + e] : 0.f;
+        bn_is[e] = bn ? c.bn_invstd[h + e] : 0.f;
+        acc_dy[e] = acc_dyx[e] = 0.f;
         al[e] = clampf(c.alpha[h + e], SP_ALPHA_LO, SP_ALPHA_HI);
         oma[e] = 1.0f - al[e];
         if (ADAPT) {
@@ -166,13 +174,14 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
     const bool drop = c.p_drop > 0.0f;
 
     for (int t0 = T - 1; t0 >= 0; t0 -= U) {
-        float g[U][VEC], up[U][VEC], wp[U][VEC];
+        float g[U][VEC], up[U][VEC], wp[U][VEC], xr[U][VEC];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 - j;
             if (t >= 0) {
                 const int tt = d ? (T - 1 - t) : t;
                 ldv<VEC>(g[j], c.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + h);
+                if (bn) ldv<VEC>(xr[j], c.bn_x + ((size_t)b * T + tt) * H + h);
                 if (t > 0) {
                     ldv<VEC>(up[j], c.u_save + ((size_t)bp * T + (t - 1)) * H + h);
                     if (ADAPT) ldv<VEC>(wp[j], c.w_save + ((size_t)bp * T + (t - 1)) * H + h);
@@ -205,6 +214,10 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
                 float du = boxcar_gate(ds, xs) + al[e] * du_n[e];            // snns.py:33-35
                 if (ADAPT) du = du + pa[e] * dw_n[e];
                 dwx[e] = oma[e] * du;
+                if (bn) {  // BatchNorm backward's column sums (dy = dWx, xhat = (x - mean) * invstd)
+                    acc_dy[e] += dwx[e];
+                    acc_dyx[e] += dwx[e] * ((xr[j][e] - bn_mu[e]) * bn_is[e]);
+                }
                 const float q = up[j][e] - sp[e];
                 acc_al[e] += du * (q - u_t[e]);  // d u_t / d alpha = (q - u_t)/(1-alpha); scaled at the end
                 if (ADAPT) {
@@ -229,6 +242,10 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
         stv<VEC>(ws + plane, acc_be);
         stv<VEC>(ws + 2 * plane, acc_a);
         stv<VEC>(ws + 3 * plane, acc_b);
+    }
+    if (bn) {
+        stv<VEC>(ws + 4 * plane, acc_dy);
+        stv<VEC>(ws + 5 * plane, acc_dyx);
     }
 }
 
@@ -327,7 +344,10 @@ __global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int 
                                                          const float* __restrict__ u_save,
                                                          const float* __restrict__ alpha,
                                                          const float* __restrict__ u0, float* __restrict__ dWx,
-                                                         float* __restrict__ dalpha_ws) {
+                                                         float* __restrict__ dalpha_ws,
+                                                         const float* __restrict__ bn_x,
+                                                         const float* __restrict__ bn_mean,
+                                                         const float* __restrict__ bn_invstd) {
     __shared__ float us[RT * (64 * NW + 1)];
     __shared__ float gs[64 * NW];
     const int lane = threadIdx.x;
@@ -339,6 +359,11 @@ __global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int 
     gs[lane] = act ? g_out[(size_t)b * C + cc] : 0.f;
     const float* ur = u_save + (size_t)b * T * C + cc;
     float du = 0.f, acc = 0.f;
+    // BatchNorm backward's column sums folded in (nullable): sum_t dWx and sum_t dWx*xhat per (row, class)
+    const bool bn = bn_x != nullptr;
+    const float bn_mu = bn ? bn_mean[cc] : 0.f, bn_is = bn ? bn_invstd[cc] : 0.f;
+    const float* xr = bn ? bn_x + (size_t)b * T * C + cc : nullptr;
+    float acc_dy = 0.f, acc_dyx = 0.f;
     const int nchunk = (T + RT - 1) / RT;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int c0 = ch * RT, len = min(RT, T - c0);
@@ -380,21 +405,32 @@ __global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int 
                 const int t = c0 + t0 - j;
                 uc[j] = t >= 0 ? ur[(size_t)t * C] : (t == -1 ? u0[(size_t)b * C + cc] : 0.f);
             }
-            float ev[RU];
+            float ev[RU], xv[RU];
 #pragma unroll
             for (int j = 0; j < RU; ++j) ev[j] = (t0 - j >= 0) ? us[(t0 - j) * CS + cc] : 0.f;
+#pragma unroll
+            for (int j = 0; j < RU; ++j) xv[j] = (bn && t0 - j >= 0) ? xr[(size_t)(c0 + t0 - j) * C] : 0.f;
 #pragma unroll
             for (int j = 0; j < RU; ++j) {
                 const int tl = t0 - j;
                 if (tl < 0) break;
                 du = al * du + ev[j];
-                if (act) dWx[((size_t)b * T + c0 + tl) * C + cc] = oma * du;
+                const float dwx = oma * du;
+                if (act) dWx[((size_t)b * T + c0 + tl) * C + cc] = dwx;
                 acc += du * (uc[j + 1] - uc[j]);
+                acc_dy += dwx;
+                acc_dyx += dwx * ((xv[j] - bn_mu) * bn_is);
             }
         }
         ro_barrier<NW>();
     }
-    if (act) dalpha_ws[(size_t)b * C + cc] = acc / oma;
+    if (act) {
+        dalpha_ws[(size_t)b * C + cc] = acc / oma;
+        if (bn) {
+            dalpha_ws[((size_t)B + b) * C + cc] = acc_dy;
+            dalpha_ws[((size_t)2 * B + b) * C + cc] = acc_dyx;
+        }
+    }
 }
 
 template <bool ADAPT>
@@ -454,9 +490,11 @@ extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const fl
                                const float* g_rate, const float* u_save, const float* w_save,
                                const float* alpha, const float* beta, const float* a, const float* b,
                                const float* u0, const float* w0, const float* s0, float theta,
-                               float p_drop, uint64_t seed, float* dWx, float* dparam_ws, void* stream) {
+                               float p_drop, uint64_t seed, float* dWx, float* dparam_ws, const float* bn_x,
+                               const float* bn_mean, const float* bn_invstd, void* stream) {
     SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
+    if (bn_x && (!bn_mean || !bn_invstd || !aligned16(bn_x))) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_ADLIF;
     if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !g_out || !u_save || !alpha || !u0 ||
         !s0 || !dWx || !dparam_ws)
@@ -472,6 +510,7 @@ extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const fl
     c.u_save = const_cast<float*>(u_save); c.w_save = const_cast<float*>(w_save);
     c.g_out = g_out; c.g_rate = g_rate; c.g_rate_scale = 1.0f / ((float)B * (float)T);
     c.dWx = dWx; c.dparam_ws = dparam_ws;
+    c.bn_x = bn_x; c.bn_mean = bn_mean; c.bn_invstd = bn_invstd;
     return adapt ? launch_cell<true>(true, c, (hipStream_t)stream)
                  : launch_cell<false>(true, c, (hipStream_t)stream);
 }
@@ -492,20 +531,21 @@ extern "C" int sparch_readout_fwd(int B, int T, int C, const float* Wx, const fl
     return SPARCH_OK;
 }
 
-extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* Wx,
-                                  const float* scale, const float* shift, const float* u_save,
+extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const float* bn_x,
+                                  const float* bn_mean, const float* bn_invstd, const float* u_save,
                                   const float* alpha, const float* u0, float* dWx, float* dalpha_ws,
                                   void* stream) {
     SPARCH_ENTER();
-    (void)Wx; (void)scale; (void)shift;  // dalpha uses u_{t-1}-x_t = (u_{t-1}-u_t)/(1-alpha): no re-read of Wx
+    // (dalpha uses u_{t-1}-x_t = (u_{t-1}-u_t)/(1-alpha): the projection is re-read only for BatchNorm's sums)
     if (B <= 0 || T <= 0 || C <= 0 || C > 256 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
         return SPARCH_EINVAL;
+    if (bn_x && (!bn_mean || !bn_invstd)) return SPARCH_EINVAL;
     if (C > 128)     hipLaunchKernelGGL(readout_bwd_kernel<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                                        alpha, u0, dWx, dalpha_ws);
+                                        alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
     else if (C > 64) hipLaunchKernelGGL(readout_bwd_kernel<2>, dim3(B), dim3(128), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                                        alpha, u0, dWx, dalpha_ws);
+                                        alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
     else hipLaunchKernelGGL(readout_bwd_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                       alpha, u0, dWx, dalpha_ws);
+                       alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

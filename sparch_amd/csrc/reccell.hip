@@ -107,6 +107,9 @@ struct RecArgs {
     // backward
     const float* g_out; const float* g_rate; float g_rate_scale;
     float* dWx; uint16_t* s_prev16; float* dparam_ws;
+    // BatchNorm backward folded in (nullable): raw projection (B,T,H) + per-column statistics; the kernel then
+    // also leaves sum_t dWx and sum_t dWx*xhat per (row, column) in planes 6 and 7 of dparam_ws
+    const float* bn_x; const float* bn_mean; const float* bn_invstd;
     // hand-off
     u64* chan; char* ring; unsigned* status;
 };
@@ -526,10 +529,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
     // per-thread neuron constants (alpha, beta, a, b, rate gradient of the thread's 4 columns): kept in LDS
     // and re-read each step — the 8-wave kernel's 256-register budget has no room to hold them
-    __shared__ __attribute__((aligned(16))) f32x4 pconst[5][256];
+    __shared__ __attribute__((aligned(16))) f32x4 pconst[7][256];  // + BatchNorm mean, invstd of the columns
     // running parameter-gradient partial sums (alpha, beta, a, b) of the thread's 4 columns: touched once per
     // step, off the critical path -> LDS, so that the hot loop's registers do not spill
-    __shared__ __attribute__((aligned(16))) f32x4 pacc[4][256];
+    __shared__ __attribute__((aligned(16))) f32x4 pacc[6][256];  // + BatchNorm's sum dWx, sum dWx*xhat
     __shared__ int abort_flag[2];
 
     const int tid = threadIdx.x;
@@ -572,7 +575,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             c_gr[e] = a.g_rate ? a.g_rate[(size_t)d * H + colc + e] * a.g_rate_scale : 0.0f;
         }
         pconst[0][tid] = c_al; pconst[1][tid] = c_be; pconst[2][tid] = c_a; pconst[3][tid] = c_b; pconst[4][tid] = c_gr;
+        if (a.bn_x) { pconst[5][tid] = ld4(a.bn_mean + colc); pconst[6][tid] = ld4(a.bn_invstd + colc); }
     }
+    const bool bn = a.bn_x != nullptr;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         du_n[e] = dw_n[e] = 0.f;
@@ -592,6 +597,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
         }
         pacc[0][tid] = v_al; pacc[1][tid] = v_be; pacc[2][tid] = v_a; pacc[3][tid] = v_b;
+        if (bn) {
+            pacc[4][tid] = a.t_end < T ? ld4(ws + 6 * plane) : z4;
+            pacc[5][tid] = a.t_end < T ? ld4(ws + 7 * plane) : z4;
+        }
     }
     {
         const f32x4 v = ld4(a.u_save + ((size_t)bpc * T + (a.t_end - 1)) * H + colc);
@@ -606,9 +615,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
 
     const bool drop = a.p_drop > 0.0f;
-    auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp) {
+    auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp, f32x4& xr) {
         const int tt = d ? (T - 1 - t) : t;
         g = ld4(a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc);
+        if (bn) xr = ld4(a.bn_x + ((size_t)b * T + tt) * H + colc);
         if (t > 0) {
             up = ld4(a.u_save + ((size_t)bpc * T + (t - 1)) * H + colc);
             if (ADAPT) wp = ld4(a.w_save + ((size_t)bpc * T + (t - 1)) * H + colc);
@@ -617,20 +627,20 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             if (ADAPT) wp = ld4(a.w0 + (size_t)bpc * H + colc);
         }
     };
-    f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f};
+    f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f}, xr_nx = {0.f, 0.f, 0.f, 0.f};
     f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     g_nx = up_nx = zero4;
-    if (pw) load_step(a.t_end - 1, g_nx, up_nx, wp_nx);
+    if (pw) load_step(a.t_end - 1, g_nx, up_nx, wp_nx, xr_nx);
     // (Unlike the forward, holding this kernel's fp32 stores / prefetch back until after the tag poll does
     // not pay: measured 16.8k -> 18.2k cycles per step, the deferred traffic then competes with the tile loads.)
     PROF_DECL
 
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
         PROF_STAMP(-1);
-        const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx;
+        const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx, xrv = xr_nx;
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
-        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx);
+        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 
         if (t + 1 < T && !EXT) {
             // ---- the dWx_{t+1} tiles of this wave's producers: load, re-load what has not landed yet
@@ -797,6 +807,16 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
             pacc[0][pt] = v_al;
             if (ADAPT) { pacc[1][pt] = v_be; pacc[2][pt] = v_a; pacc[3][pt] = v_b; }
+            if (bn) {  // BatchNorm backward's column sums (dy = dWx, xhat = (x - mean) * invstd)
+                f32x4 v_dy = pacc[4][pt], v_dyx = pacc[5][pt];
+                const f32x4 mu = pconst[5][pt], is = pconst[6][pt];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v_dy[e] += dwx[e];
+                    v_dyx[e] += dwx[e] * ((xrv[e] - mu[e]) * is[e]);
+                }
+                pacc[4][pt] = v_dy; pacc[5][pt] = v_dyx;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -824,6 +844,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             st4(ws + 2 * plane, pacc[2][tid]);
             st4(ws + 3 * plane, pacc[3][tid]);
             v.x = dw_n[0]; v.y = dw_n[1]; v.z = dw_n[2]; v.w = dw_n[3]; st4(ws + 5 * plane, v);
+        }
+        if (bn) {
+            st4(ws + 6 * plane, pacc[4][tid]);
+            st4(ws + 7 * plane, pacc[5][tid]);
         }
     }
 }
@@ -1321,9 +1345,12 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
                                    const float* b, const float* vpack_t, const float* u0,
                                    const float* w0, const float* s0, float theta, float p_drop,
                                    uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
+                                   const float* bn_x, const float* bn_mean, const float* bn_invstd,
                                    void* chan, size_t chan_bytes, uint32_t* status,
                                    int steps_per_launch, void* stream) {
     SPARCH_ENTER();
+    if (bn_x && (!bn_mean || !bn_invstd || !aligned16(bn_x) || !aligned16(bn_mean) || !aligned16(bn_invstd)))
+        return SPARCH_EINVAL;
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
@@ -1341,6 +1368,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws;
+    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<true>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }
@@ -1421,8 +1449,12 @@ extern "C" int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H,
                                         const float* alpha, const float* beta, const float* a, const float* b,
                                         const float* rec, const float* u0, const float* w0, const float* s0,
                                         float theta, float p_drop, uint64_t seed, float* dWx,
-                                        uint16_t* s_prev16, float* dparam_ws, float* dwx_step, void* stream) {
+                                        uint16_t* s_prev16, float* dparam_ws, const float* bn_x,
+                                        const float* bn_mean, const float* bn_invstd, float* dwx_step,
+                                        void* stream) {
     SPARCH_ENTER();
+    if (bn_x && (!bn_mean || !bn_invstd || !aligned16(bn_x) || !aligned16(bn_mean) || !aligned16(bn_invstd)))
+        return SPARCH_EINVAL;
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2) || t < 0 || t >= T) return SPARCH_EINVAL;
@@ -1440,6 +1472,7 @@ extern "C" int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H,
     r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws; r.dwx_step = dwx_step;
+    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd;
     const unsigned grid = (unsigned)(r.n_ct * r.n_rt_total);
     hipStream_t st = (hipStream_t)stream;
     if (adapt) hipLaunchKernelGGL((rec_bwd_kernel<true, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);

@@ -25,6 +25,10 @@ USE_SPIKE16 = os.environ.get("SPARCH_SPIKE16", "1") != "0"
 # Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
 
+# BatchNorm backward's column sums (dbeta, dgamma) come out of the cell's backward kernel instead of a
+# separate pass over dy and x (SPARCH_FUSE_BN_SUMS=0: the separate sparch_bn_bwd_reduce pass, for comparison).
+FUSE_BN_SUMS = os.environ.get("SPARCH_FUSE_BN_SUMS", "1") != "0"
+
 BN_MOMENTUM = 0.05  # snns.py:240
 # SyncBN for data-parallel runs (off by default = standard DDP semantics: per-rank statistics).
 # {"group": process group or None, "world": n}: BatchNorm then normalises with the statistics of the GLOBAL
@@ -273,7 +277,7 @@ def _finish_param_grads(ws, rows, H, raws, lims):
 
     n = len(raws)
     outs = [torch.empty(H, dtype=torch.float32, device=ws.device) for _ in range(n)]
-    raw_arr = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    raw_arr = (ctypes.c_void_p * n)(*[(r.data_ptr() if r is not None else None) for r in raws])  # None: no clamp gate
     out_arr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     lim_arr = (ctypes.c_float * (2 * n))(*[v for lo_hi in lims for v in lo_hi])
     check(lib.sparch_colsum_clamped(n, rows, H, ptr(ws), raw_arr, lim_arr, out_arr, _stream()),
@@ -318,18 +322,22 @@ class _Norm:
         return Wx_raw, None, None, None
 
     @staticmethod
-    def backward(mode, dy, Wx_raw, weight, saved, training):
-        """dy (M,H) grad wrt the normalised projection -> (dx_raw, dweight, dbias). May overwrite dy."""
+    def backward(mode, dy, Wx_raw, weight, saved, training, sums=None):
+        """dy (M,H) grad wrt the normalised projection -> (dx_raw, dweight, dbias). May overwrite dy.
+        sums = (dbeta, dgamma) when the cell's backward kernel already produced BatchNorm's column sums."""
         M, H = dy.shape
         dev = dy.device
         if mode == "batchnorm":
             mean, invstd = saved  # batch statistics (train) or running statistics (eval)
-            dgamma = torch.empty(H, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(H, dtype=torch.float32, device=dev)
-            nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_bn_bwd_reduce(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(dgamma),
-                                           ptr(dbeta), ptr(ws), nbytes, _stream()), "sparch_bn_bwd_reduce")
+            if sums is not None:
+                dbeta, dgamma = sums
+            else:
+                dgamma = torch.empty(H, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(H, dtype=torch.float32, device=dev)
+                nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+                check(lib.sparch_bn_bwd_reduce(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(dgamma),
+                                               ptr(dbeta), ptr(ws), nbytes, _stream()), "sparch_bn_bwd_reduce")
             if training and SYNC_BN is not None and SYNC_BN["world"] > 1:
                 import torch.distributed as dist
 
@@ -425,24 +433,26 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
 
 
 def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, theta, p_drop, seed,
-                  steps_per_launch=None):
+                  steps_per_launch=None, bn=None):
     """Reverse-time pass.  Returns dWx (B*dirs,T,H) [virtual rows, original time index],
-    param grads dict (alpha[,beta,a,b][,V])."""
+    param grads dict (alpha[,beta,a,b][,V]) — plus, with bn = (Wx_raw (B,T,H), mean, invstd), the entry
+    "bn_sums" = (dbeta, dgamma): BatchNorm backward's column sums, accumulated by the same kernel."""
     Bp = B * dirs
     dev = g_out.device
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
     u_save, w_save = saved
     dWx = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
-    n_planes = 6 if recurrent else 4
-    ws = torch.empty(n_planes, Bp, H, dtype=torch.float32, device=dev)
+    n_base = 6 if recurrent else 4
+    ws = torch.empty(n_base + (2 if bn is not None else 0), Bp, H, dtype=torch.float32, device=dev)
+    bn_x, bn_mean, bn_invstd = bn if bn is not None else (None, None, None)
     grads = {}
     if not recurrent:
         tok = timer.start(f"cell_bwd[{kind}]")
         check(lib.sparch_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
                                   ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0),
-                                  ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(ws), _stream()),
-              "sparch_cell_bwd")
+                                  ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(ws), ptr(bn_x), ptr(bn_mean),
+                                  ptr(bn_invstd), _stream()), "sparch_cell_bwd")
         timer.stop(tok)
     else:
         V = p["V"]
@@ -461,7 +471,8 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                                                    ptr(w_save), ptr(p["alpha"]), ptr(p.get("beta")),
                                                    ptr(p.get("a")), ptr(p.get("b")), ptr(rec), ptr(u0), ptr(w0),
                                                    ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(s_prev), ptr(ws),
-                                                   ptr(dwx_step), _stream()), "sparch_rec_cell_step_bwd")
+                                                   ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(dwx_step),
+                                                   _stream()), "sparch_rec_cell_step_bwd")
             timer.stop(tok)
         else:
             vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
@@ -473,8 +484,8 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
             check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
                                           ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
                                           ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
-                                          ptr(s_prev), ptr(ws), ptr(chan), nbytes, ptr(status_word(dev)), L,
-                                          _stream()), "sparch_rec_cell_bwd")
+                                          ptr(s_prev), ptr(ws), ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(chan),
+                                          nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_bwd")
             timer.stop(tok)
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
         # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
@@ -492,6 +503,8 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     lims = [ALPHA_LIM] + ([BETA_LIM, A_LIM, B_LIM] if adaptive else [])
     outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names], lims)
     grads.update(dict(zip(names, outs)))
+    if bn is not None:  # column sums of the two BatchNorm planes (no clamp gate)
+        grads["bn_sums"] = tuple(_finish_param_grads(ws[n_base:], Bp, H, [None, None], [(0.0, 0.0)] * 2))
     return dWx, grads
 
 
@@ -554,8 +567,9 @@ class SpikingLayerFn(torch.autograd.Function):
             g_rate = _f32c(g_rate)
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
         p = {k_: v for k_, v in p.items() if v is not None}
+        bn = (Wx_raw, ctx.nsaved[0], ctx.nsaved[1]) if (norm == "batchnorm" and FUSE_BN_SUMS and H % 4 == 0) else None
         dWx, pg = cell_backward(kind, g_s, g_rate, p, u0, w0, s0, ctx.cell_saved, B=B, dirs=dirs, T=T, H=H,
-                                theta=cfg["theta"], p_drop=cfg["p_drop"], seed=cfg["seed"])
+                                theta=cfg["theta"], p_drop=cfg["p_drop"], seed=cfg["seed"], bn=bn)
         ctx.cell_saved = None
         if dirs == 2:  # both directions share the projection rows (snns.py:252-254)
             dy = torch.empty(B, T, H, dtype=torch.float32, device=dev)
@@ -563,7 +577,7 @@ class SpikingLayerFn(torch.autograd.Function):
         else:
             dy = dWx
         dy = dy.view(M, H)
-        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"], sums=pg.get("bn_sums"))
         in_scale = cfg.get("in_spike_scale")
         x16 = cfg.get("in_spike16") if (in_scale is not None and USE_SPIKE16) else None
         if x16 is not None and USE_SPIKE_GEMM:
@@ -620,12 +634,16 @@ class ReadoutLayerFn(torch.autograd.Function):
         dev = x2.device
         g_out = _f32c(g_out)
         dWx = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        ws = torch.empty(1, B, C, dtype=torch.float32, device=dev)
-        check(lib.sparch_readout_bwd(B, T, C, ptr(g_out), None, None, None, ptr(u_save), ptr(alpha), ptr(u0),
-                                     ptr(dWx), ptr(ws), _stream()), "sparch_readout_bwd")
+        fuse = norm == "batchnorm" and FUSE_BN_SUMS
+        ws = torch.empty(3 if fuse else 1, B, C, dtype=torch.float32, device=dev)
+        check(lib.sparch_readout_bwd(B, T, C, ptr(g_out), ptr(Wx_raw) if fuse else None,
+                                     ptr(ctx.nsaved[0]) if fuse else None, ptr(ctx.nsaved[1]) if fuse else None,
+                                     ptr(u_save), ptr(alpha), ptr(u0), ptr(dWx), ptr(ws), _stream()),
+              "sparch_readout_bwd")
         (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
+        sums = tuple(_finish_param_grads(ws[1:], B, C, [None, None], [(0.0, 0.0)] * 2)) if fuse else None
         dy = dWx.view(M, C)
-        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"], sums=sums)
         in_scale = cfg.get("in_spike_scale")
         x16 = cfg.get("in_spike16") if (in_scale is not None and USE_SPIKE16) else None
         if x16 is not None and USE_SPIKE_GEMM:
