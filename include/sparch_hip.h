@@ -197,10 +197,16 @@ int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
                     const float* scale, const float* shift, const float* alpha,
                     const float* beta, const float* a, const float* b, const float* u0,
                     const float* w0, const float* s0, float theta, float p_drop,
-                    uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
-                    uint32_t* spike_count, void* stream);
+                    uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save, void* w_save,
+                    int save_bf16, uint32_t* spike_count, void* stream);
 
-/* g_out (B,T,H*dirs) upstream gradient of s_out; g_rate (H*dirs) upstream gradient of the
+/* save_bf16 (forward and backward alike): u_save / w_save are (Bp,T,H) bf16 instead of fp32 — half the bytes
+ * of the two largest tensors a layer keeps for its backward pass.  The stored membrane potential is rounded
+ * so that the backward's three discrete decisions (spike u-theta > 0, box-car edges) are EXACTLY the fp32
+ * ones (csrc/common.h save_u16): recomputed spikes never flip, dWx / dW / dV are unchanged, only the
+ * continuous uses of u and w (dalpha, dbeta, da) carry the 2^-9 relative rounding.  The recurrent kernels
+ * accept it for whole-sequence launches only (steps_per_launch >= T).
+ * g_out (B,T,H*dirs) upstream gradient of s_out; g_rate (H*dirs) upstream gradient of the
  * firing rates (NULL = none).  dWx (Bp,T,H): gradient w.r.t. the normalised projection,
  * virtual-row order but ORIGINAL time index (so rows b and b+B add elementwise).
  * dparam_ws: (4,Bp,H) per-row partials of (dalpha,dbeta,da,db); finish with
@@ -210,7 +216,7 @@ int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
  * xhat = (x - mean)*invstd, per (row, column) in planes 4 and 5 of dparam_ws ((6,Bp,H) then): their
  * column sums are BatchNorm's dbeta / dgamma — no separate pass over dy and x.            */
 int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
-                    const float* g_rate, const float* u_save, const float* w_save,
+                    const float* g_rate, const void* u_save, const void* w_save, int save_bf16,
                     const float* alpha, const float* beta, const float* a, const float* b,
                     const float* u0, const float* w0, const float* s0, float theta,
                     float p_drop, uint64_t seed, float* dWx, float* dparam_ws, const float* bn_x,
@@ -238,9 +244,9 @@ int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx
                         const float* beta, const float* a, const float* b,
                         const float* vpack, const float* rec0, const float* u0,
                         const float* w0, const float* s0, float theta, float p_drop,
-                        uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save,
-                        float* w_save, uint32_t* spike_count, void* chan, size_t chan_bytes,
-                        uint32_t* status, int steps_per_launch, void* stream);
+                        uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save,
+                        void* w_save, int save_bf16, uint32_t* spike_count, void* chan,
+                        size_t chan_bytes, uint32_t* status, int steps_per_launch, void* stream);
 /* Backward: each step's 32x32 dWx tile is handed to the other workgroups through `chan`.
  * s_prev16 (Bp,T,H) receives s_{t-1} as a bf16 plane (binary for t >= 1, a zero row at
  * t = 0: the non-binary s0 term is added by the caller) for dV = s_prev^T * dWx
@@ -248,7 +254,7 @@ int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx
  * (dalpha,dbeta,da,db) + the du / dw carries of chunked launches; with bn_x / bn_mean / bn_invstd
  * non-NULL (see sparch_cell_bwd) planes 6 and 7 receive BatchNorm's sums ((8,Bp,H) then).   */
 int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
-                        const float* g_rate, const float* u_save, const float* w_save,
+                        const float* g_rate, const void* u_save, const void* w_save, int save_bf16,
                         const float* alpha, const float* beta, const float* a,
                         const float* b, const float* vpack_t, const float* u0,
                         const float* w0, const float* s0, float theta, float p_drop,

@@ -60,16 +60,16 @@ PROTOTYPES = {
     "sparch_layernorm_fwd": (c_int, [c_int, c_int, P, P, P, c_float, P, P, P, P]),
     "sparch_layernorm_bwd": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sparch_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P,
-                                c_float, c_float, c_uint64, P, P, P, P, P, P]),
-    "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
+                                c_float, c_float, c_uint64, P, P, P, P, c_int, P, P]),
+    "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P,
                                 c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_vpack_bytes": (c_size_t, [c_int]),
     "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
     "sparch_vmask": (c_int, [c_int, P, P, P]),
     "sparch_rec_chan_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sparch_rec_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
-                                    c_float, c_float, c_uint64, P, P, P, P, P, P, c_size_t, P, c_int, P]),
-    "sparch_rec_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                    c_float, c_float, c_uint64, P, P, P, P, c_int, P, P, c_size_t, P, c_int, P]),
+    "sparch_rec_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P,
                                     c_float, c_float, c_uint64, P, P, P, P, P, P, P, c_size_t, P, c_int, P]),
     "sparch_rec_cell_step_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
                                          c_float, c_float, c_uint64, P, P, P, P, P, P, P]),

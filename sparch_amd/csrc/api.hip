@@ -4,7 +4,10 @@
 static thread_local int g_last_hip_error = 0;
 void sparch_note_hip_error(int e) { g_last_hip_error = e; }
 
-extern "C" int sparch_abi_version(void) { return 2; }  // 2: bf16 spike planes (s16_out, s_prev16, spike16 GEMMs), adam
+// 2: bf16 spike planes (s16_out, s_prev16, spike16 GEMMs), adam
+// 3: step variants of the recurrent cells (any hidden size), BatchNorm sums out of the cell backward kernels,
+//    optional bf16 saved states, device-side skip words on adam / bn_finalize, readout up to 256 classes
+extern "C" int sparch_abi_version(void) { return 3; }
 
 extern "C" const char* sparch_last_hip_error(void) {
     return hipGetErrorString((hipError_t)g_last_hip_error);

@@ -36,6 +36,7 @@ struct CellArgs {
     // BatchNorm backward folded in (nullable): the raw projection and its per-column statistics; the kernel
     // then also leaves sum_t dWx and sum_t dWx*xhat per (row, column) in two more planes of dparam_ws
     const float* bn_x; const float* bn_mean; const float* bn_invstd;
+    int save16;  // u_save / w_save hold bf16 (common.h save_u16) instead of fp32
 };
 
 template <int VEC>
@@ -45,6 +46,37 @@ __device__ __forceinline__ void ldv(float (&d)[VEC], const float* p) {
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     } else {
         d[0] = p[0];
+    }
+}
+// saved states (u, w): element index i of an fp32 or bf16 array
+template <int VEC>
+__device__ __forceinline__ void ld_saved(float (&d)[VEC], const float* base, size_t i, bool s16) {
+    if (!s16) { ldv<VEC>(d, base + i); return; }
+    const unsigned short* q = reinterpret_cast<const unsigned short*>(base) + i;
+    if constexpr (VEC == 4) {
+        const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = bf16_to_f32((unsigned short)(raw >> (16 * e)));
+    } else {
+        d[0] = bf16_to_f32(q[0]);
+    }
+}
+template <int VEC, bool IS_U>
+__device__ __forceinline__ void st_saved(float* base, size_t i, const float (&d)[VEC], bool s16, float theta) {
+    if (!s16) {
+        if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(base + i) = f32x4{d[0], d[1], d[2], d[3]};
+        else base[i] = d[0];
+        return;
+    }
+    unsigned short* q = reinterpret_cast<unsigned short*>(base) + i;
+    if constexpr (VEC == 4) {
+        unsigned long long raw = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            raw |= (unsigned long long)(IS_U ? save_u16(d[e], theta) : f32_to_bf16_rne(d[e])) << (16 * e);
+        *reinterpret_cast<unsigned long long*>(q) = raw;
+    } else {
+        q[0] = IS_U ? save_u16(d[0], theta) : f32_to_bf16_rne(d[0]);
     }
 }
 template <int VEC>
@@ -57,7 +89,7 @@ __device__ __forceinline__ void stv(float* p, const float (&d)[VEC]) {
     }
 }
 
-template <bool ADAPT, int VEC>
+template <bool ADAPT, int VEC, bool S16>
 __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
     constexpr int U = Depth<VEC>::U;
     const int HQ = c.H / VEC;
@@ -127,8 +159,8 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) c.s16_out[o + e] = so[e] != 0.0f ? (uint16_t)0x3F80 : (uint16_t)0;
             }
-            if (c.u_save) stv<VEC>(c.u_save + ((size_t)bp * T + t) * H + h, u);
-            if (ADAPT && c.w_save) stv<VEC>(c.w_save + ((size_t)bp * T + t) * H + h, w);
+            if (c.u_save) st_saved<VEC, true>(c.u_save, ((size_t)bp * T + t) * H + h, u, S16, c.theta);
+            if (ADAPT && c.w_save) st_saved<VEC, false>(c.w_save, ((size_t)bp * T + t) * H + h, w, S16, c.theta);
         }
     }
     if (c.spike_count) {
@@ -138,7 +170,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
     }
 }
 
-template <bool ADAPT, int VEC>
+template <bool ADAPT, int VEC, bool S16>
 __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
     constexpr int U = Depth<VEC>::U;
     const int HQ = c.H / VEC;
@@ -170,11 +202,15 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
         du_n[e] = dw_n[e] = 0.f;
         acc_al[e] = acc_be[e] = acc_a[e] = acc_b[e] = 0.f;
     }
-    ldv<VEC>(u_t, c.u_save + ((size_t)bp * T + (T - 1)) * H + h);
+    constexpr bool s16 = S16;  // compile-time: a run-time flag here breaks up the batched prefetch loads
+    ld_saved<VEC>(u_t, c.u_save, ((size_t)bp * T + (T - 1)) * H + h, s16);
     const bool drop = c.p_drop > 0.0f;
 
     for (int t0 = T - 1; t0 >= 0; t0 -= U) {
         float g[U][VEC], up[U][VEC], wp[U][VEC], xr[U][VEC];
+        // bf16 saves: the raw words are fetched here and unpacked at their use, so that the U steps' loads stay
+        // one batch (unpacking next to each load made hipcc wait for every load in turn: 2x the kernel time)
+        [[maybe_unused]] unsigned long long upr[U], wpr[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 - j;
@@ -182,9 +218,16 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
                 const int tt = d ? (T - 1 - t) : t;
                 ldv<VEC>(g[j], c.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + h);
                 if (bn) ldv<VEC>(xr[j], c.bn_x + ((size_t)b * T + tt) * H + h);
-                if (t > 0) {
-                    ldv<VEC>(up[j], c.u_save + ((size_t)bp * T + (t - 1)) * H + h);
-                    if (ADAPT) ldv<VEC>(wp[j], c.w_save + ((size_t)bp * T + (t - 1)) * H + h);
+                if constexpr (S16 && VEC == 4) {
+                    // unconditional raw fetch (row t-1, or row 0 again at t = 0 where u0 / w0 are read below): no
+                    // branch between the loads of a batch
+                    const size_t i = ((size_t)bp * T + (t > 0 ? t - 1 : 0)) * H + h;
+                    upr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.u_save) + i);
+                    if (ADAPT) wpr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.w_save) + i);
+                } else if (t > 0) {
+                    const size_t i = ((size_t)bp * T + (t - 1)) * H + h;
+                    ld_saved<VEC>(up[j], c.u_save, i, s16);
+                    if (ADAPT) ld_saved<VEC>(wp[j], c.w_save, i, s16);
                 } else {
                     ldv<VEC>(up[j], c.u0 + (size_t)bp * H + h);
                     if (ADAPT) ldv<VEC>(wp[j], c.w0 + (size_t)bp * H + h);
@@ -198,6 +241,18 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
             const int tt = d ? (T - 1 - t) : t;
             const size_t o = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
             float sp[VEC], dwx[VEC];
+            if constexpr (S16 && VEC == 4) {
+                if (t > 0) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        up[j][e] = bf16_to_f32((unsigned short)(upr[j] >> (16 * e)));
+                        if (ADAPT) wp[j][e] = bf16_to_f32((unsigned short)(wpr[j] >> (16 * e)));
+                    }
+                } else {  // last step of the reverse pass: the exact fp32 initial states
+                    ldv<VEC>(up[j], c.u0 + (size_t)bp * H + h);
+                    if (ADAPT) ldv<VEC>(wp[j], c.w0 + (size_t)bp * H + h);
+                }
+            }
             if (t > 0) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) sp[e] = (up[j][e] - c.theta) > 0.0f ? 1.0f : 0.0f;
@@ -441,13 +496,17 @@ int launch_cell(bool bwd, CellArgs& c, hipStream_t st) {
     const bool vec4 = vec_ok && work >= (long long)256 * 8 * 64 * 4;
     const long long threads = vec4 ? work / 4 : work;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
+#define SP_CELL_LAUNCH(KERNEL, S16)                                                                     \
+    do {                                                                                                \
+        if (vec4) hipLaunchKernelGGL((KERNEL<ADAPT, 4, S16>), dim3(blocks), dim3(256), 0, st, c);       \
+        else      hipLaunchKernelGGL((KERNEL<ADAPT, 1, S16>), dim3(blocks), dim3(256), 0, st, c);       \
+    } while (0)
     if (!bwd) {
-        if (vec4) hipLaunchKernelGGL((cell_fwd_kernel<ADAPT, 4>), dim3(blocks), dim3(256), 0, st, c);
-        else      hipLaunchKernelGGL((cell_fwd_kernel<ADAPT, 1>), dim3(blocks), dim3(256), 0, st, c);
+        if (c.save16) SP_CELL_LAUNCH(cell_fwd_kernel, true); else SP_CELL_LAUNCH(cell_fwd_kernel, false);
     } else {
-        if (vec4) hipLaunchKernelGGL((cell_bwd_kernel<ADAPT, 4>), dim3(blocks), dim3(256), 0, st, c);
-        else      hipLaunchKernelGGL((cell_bwd_kernel<ADAPT, 1>), dim3(blocks), dim3(256), 0, st, c);
+        if (c.save16) SP_CELL_LAUNCH(cell_bwd_kernel, true); else SP_CELL_LAUNCH(cell_bwd_kernel, false);
     }
+#undef SP_CELL_LAUNCH
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
@@ -464,8 +523,8 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
                                const float* scale, const float* shift, const float* alpha,
                                const float* beta, const float* a, const float* b, const float* u0,
                                const float* w0, const float* s0, float theta, float p_drop,
-                               uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
-                               uint32_t* spike_count, void* stream) {
+                               uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save, void* w_save,
+                               int save_bf16, uint32_t* spike_count, void* stream) {
     SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_ADLIF;
@@ -481,13 +540,14 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
     c.alpha = alpha; c.beta = beta; c.a = a; c.b = b;
     c.u0 = u0; c.w0 = w0; c.s0 = s0;
     c.theta = theta; c.p_drop = p_drop; c.inv_keep = 1.0f / (1.0f - p_drop); c.seed = seed;
-    c.s_out = s_out; c.s16_out = s16_out; c.u_save = u_save; c.w_save = w_save; c.spike_count = spike_count;
+    c.s_out = s_out; c.s16_out = s16_out; c.u_save = (float*)u_save; c.w_save = (float*)w_save;
+    c.save16 = save_bf16 != 0; c.spike_count = spike_count;
     return adapt ? launch_cell<true>(false, c, (hipStream_t)stream)
                  : launch_cell<false>(false, c, (hipStream_t)stream);
 }
 
 extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
-                               const float* g_rate, const float* u_save, const float* w_save,
+                               const float* g_rate, const void* u_save, const void* w_save, int save_bf16,
                                const float* alpha, const float* beta, const float* a, const float* b,
                                const float* u0, const float* w0, const float* s0, float theta,
                                float p_drop, uint64_t seed, float* dWx, float* dparam_ws, const float* bn_x,
@@ -507,7 +567,8 @@ extern "C" int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const fl
     c.alpha = alpha; c.beta = beta; c.a = a; c.b = b;
     c.u0 = u0; c.w0 = w0; c.s0 = s0;
     c.theta = theta; c.p_drop = p_drop; c.inv_keep = 1.0f / (1.0f - p_drop); c.seed = seed;
-    c.u_save = const_cast<float*>(u_save); c.w_save = const_cast<float*>(w_save);
+    c.u_save = (float*)const_cast<void*>(u_save); c.w_save = (float*)const_cast<void*>(w_save);
+    c.save16 = save_bf16 != 0;
     c.g_out = g_out; c.g_rate = g_rate; c.g_rate_scale = 1.0f / ((float)B * (float)T);
     c.dWx = dWx; c.dparam_ws = dparam_ws;
     c.bn_x = bn_x; c.bn_mean = bn_mean; c.bn_invstd = bn_invstd;

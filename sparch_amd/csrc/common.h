@@ -43,6 +43,32 @@ __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return
 // outside the box and a NaN x (both comparisons false) passes the gradient through.
 __device__ __forceinline__ float boxcar_gate(float g, float x) { return (x <= -0.5f || x > 0.5f) ? 0.0f : g; }
 
+// ---- optional bf16 storage of the states saved for the backward pass (u, w): half the bytes of the two
+// largest tensors a spiking layer keeps.  The backward takes three DISCRETE decisions from a saved membrane
+// potential — the spike u - theta > 0 and the box-car edges u - theta <= -0.5, u - theta > 0.5 — and those
+// must not change, or recomputed spikes would flip.  save_u16 rounds to nearest-even and, when that moved
+// the value onto or across one of the three thresholds, steps one bf16 ulp back towards u: every decision is
+// then EXACTLY the fp32 one (flip rate 0 by construction); only the continuous uses of u and w (the alpha,
+// beta, a gradients) see the 2^-9 relative rounding.
+__device__ __forceinline__ unsigned decisions_of(float u, float theta) {
+    const float x = u - theta;
+    return (x > 0.0f ? 1u : 0u) | (x <= -0.5f ? 2u : 0u) | (x > 0.5f ? 4u : 0u);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+__device__ __forceinline__ unsigned short save_u16(float u, float theta) {
+    unsigned short b = f32_to_bf16_rne(u);
+    const float v = bf16_to_f32(b);
+    if (decisions_of(v, theta) != decisions_of(u, theta) && (b & 0x7FFFu) != 0u) {
+        const bool up = v < u;                     // move towards u
+        const bool neg = (b & 0x8000u) != 0u;
+        b = (unsigned short)((up != neg) ? b + 1 : b - 1);
+    }
+    return b;
+}
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
     return fminf(fmaxf(x, lo), hi);
 }

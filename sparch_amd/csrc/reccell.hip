@@ -110,6 +110,7 @@ struct RecArgs {
     // BatchNorm backward folded in (nullable): raw projection (B,T,H) + per-column statistics; the kernel then
     // also leaves sum_t dWx and sum_t dWx*xhat per (row, column) in planes 6 and 7 of dparam_ws
     const float* bn_x; const float* bn_mean; const float* bn_invstd;
+    int save16;  // u_save / w_save hold bf16 (common.h save_u16); whole-sequence launches only
     // hand-off
     u64* chan; char* ring; unsigned* status;
 };
@@ -139,6 +140,24 @@ __device__ u64 g_rec_prof[2][512][8];
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// saved states (u, w) as fp32 or bf16 (element index i)
+__device__ __forceinline__ f32x4 ld4_saved(const float* base, size_t i, bool s16) {
+    if (!s16) return ld4(base + i);
+    const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(base) + i);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32((unsigned short)(raw >> (16 * e)));
+    return v;
+}
+template <bool IS_U>
+__device__ __forceinline__ void st4_saved(float* base, size_t i, f32x4 v, bool s16, float theta) {
+    if (!s16) { st4(base + i, v); return; }
+    unsigned long long raw = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        raw |= (unsigned long long)(IS_U ? save_u16(v[e], theta) : f32_to_bf16_rne(v[e])) << (16 * e);
+    *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(base) + i) = raw;
+}
 
 // Workgroup barrier for LDS hand-offs inside the time loops.  __syncthreads() also carries workgroup-scope
 // release / acquire fences on GLOBAL memory, i.e. an `s_waitcnt vmcnt(0)`: every wave would wait for the
@@ -350,8 +369,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 h.y = (pend_s[2] != 0.f ? 0x3F80u : 0u) | (pend_s[3] != 0.f ? 0x3F800000u : 0u);
                 *reinterpret_cast<u32x2*>(a.s16_out + o_s) = h;
             }
-            st4(a.u_save + ((size_t)bp * T + pend_t) * H + col, pend_u);
-            if (ADAPT) st4(a.w_save + ((size_t)bp * T + pend_t) * H + col, pend_w);
+            st4_saved<true>(a.u_save, ((size_t)bp * T + pend_t) * H + col, pend_u, a.save16, a.theta);
+            if (ADAPT) st4_saved<false>(a.w_save, ((size_t)bp * T + pend_t) * H + col, pend_w, a.save16, a.theta);
         }
         pend_t = -1;
     };
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
     }
     {
-        const f32x4 v = ld4(a.u_save + ((size_t)bpc * T + (a.t_end - 1)) * H + colc);
+        const f32x4 v = ld4_saved(a.u_save, ((size_t)bpc * T + (a.t_end - 1)) * H + colc, a.save16);
         u_t[0] = v.x; u_t[1] = v.y; u_t[2] = v.z; u_t[3] = v.w;
     }
     if (tid < 2) abort_flag[tid] = 0;
@@ -620,8 +639,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         g = ld4(a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc);
         if (bn) xr = ld4(a.bn_x + ((size_t)b * T + tt) * H + colc);
         if (t > 0) {
-            up = ld4(a.u_save + ((size_t)bpc * T + (t - 1)) * H + colc);
-            if (ADAPT) wp = ld4(a.w_save + ((size_t)bpc * T + (t - 1)) * H + colc);
+            up = ld4_saved(a.u_save, ((size_t)bpc * T + (t - 1)) * H + colc, a.save16);
+            if (ADAPT) wp = ld4_saved(a.w_save, ((size_t)bpc * T + (t - 1)) * H + colc, a.save16);
         } else {
             up = ld4(a.u0 + (size_t)bpc * H + colc);
             if (ADAPT) wp = ld4(a.w0 + (size_t)bpc * H + colc);
@@ -1316,10 +1335,12 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
                                    const float* beta, const float* a, const float* b,
                                    const float* vpack, const float* rec0, const float* u0,
                                    const float* w0, const float* s0, float theta, float p_drop,
-                                   uint64_t seed, float* s_out, uint16_t* s16_out, float* u_save, float* w_save,
-                                   uint32_t* spike_count, void* chan, size_t chan_bytes,
+                                   uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save, void* w_save,
+                                   int save_bf16, uint32_t* spike_count, void* chan, size_t chan_bytes,
                                    uint32_t* status, int steps_per_launch, void* stream) {
     SPARCH_ENTER();
+    // bf16 saved states cannot carry the exact state from one launch of a chunked forward to the next
+    if (save_bf16 && steps_per_launch < T) return SPARCH_EINVAL;
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
@@ -1334,13 +1355,14 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
     r.vpack = reinterpret_cast<const u32x4*>(vpack); r.rec0 = rec0; r.u0 = u0; r.w0 = w0; r.s0 = s0;
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
-    r.s_out = s_out; r.s16_out = s16_out; r.u_save = u_save; r.w_save = w_save; r.spike_count = spike_count;
+    r.s_out = s_out; r.s16_out = s16_out; r.u_save = (float*)u_save; r.w_save = (float*)w_save;
+    r.save16 = save_bf16 != 0; r.spike_count = spike_count;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<false>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }
 
 extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
-                                   const float* g_rate, const float* u_save, const float* w_save,
+                                   const float* g_rate, const void* u_save, const void* w_save, int save_bf16,
                                    const float* alpha, const float* beta, const float* a,
                                    const float* b, const float* vpack_t, const float* u0,
                                    const float* w0, const float* s0, float theta, float p_drop,
@@ -1365,7 +1387,8 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
     r.vpack = reinterpret_cast<const u32x4*>(vpack_t); r.u0 = u0; r.w0 = w0; r.s0 = s0;
     r.theta = theta; r.p_drop = p_drop; r.inv_keep = 1.0f / (1.0f - p_drop); r.seed = seed;
-    r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
+    r.u_save = (float*)const_cast<void*>(u_save); r.w_save = (float*)const_cast<void*>(w_save);
+    r.save16 = save_bf16 != 0;
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws;
     r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd;

@@ -29,6 +29,13 @@ DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
 # separate pass over dy and x (SPARCH_FUSE_BN_SUMS=0: the separate sparch_bn_bwd_reduce pass, for comparison).
 FUSE_BN_SUMS = os.environ.get("SPARCH_FUSE_BN_SUMS", "1") != "0"
 
+# Saved states (u, w) of the spiking layers in bf16 instead of fp32 (SPARCH_SAVE_DTYPE=bf16; BASELINE configs[4]
+# is the long-sequence bf16 case: at T=1000 the fp32 saves are 4.2 GB per layer and direction pair).  Every
+# discrete decision of the backward pass stays exactly the fp32 one (csrc/common.h save_u16), so spikes, dWx, dW
+# and dV do not change; dalpha / dbeta / da see the 2^-9 rounding of u and w: stated tolerance 2e-2 of max-abs
+# against the fp32 path (tests/test_hip_parity.py::test_bf16_saved_states_*).  Off by default.
+SAVE_BF16 = os.environ.get("SPARCH_SAVE_DTYPE", "fp32").lower() == "bf16"
+
 BN_MOMENTUM = 0.05  # snns.py:240
 # SyncBN for data-parallel runs (off by default = standard DDP semantics: per-rank statistics).
 # {"group": process group or None, "world": n}: BatchNorm then normalises with the statistics of the GLOBAL
@@ -382,15 +389,20 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
     s_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
     # the same spikes as a bf16 0/1 plane for the GEMMs of the next layer (rows must stay 16-byte aligned)
     s16 = torch.empty(B, T, H * dirs, dtype=torch.bfloat16, device=dev) if (USE_SPIKE_GEMM and USE_SPIKE16) else None
-    u_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
-    w_save = torch.empty(Bp, T, H, dtype=torch.float32, device=dev) if adaptive else None
+    L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
+    # bf16 saves: the recurrent kernels take them for whole-sequence launches only (a chunked forward resumes
+    # from the saved state, which must then be exact)
+    save16 = SAVE_BF16 and H % 4 == 0 and (not recurrent or (L >= T and not rec_step_path(H)))
+    sdt = torch.bfloat16 if save16 else torch.float32
+    u_save = torch.empty(Bp, T, H, dtype=sdt, device=dev)
+    w_save = torch.empty(Bp, T, H, dtype=sdt, device=dev) if adaptive else None
     count = torch.zeros(H * dirs, dtype=torch.int32, device=dev)
     if not recurrent:
         tok = timer.start(f"cell_fwd[{kind}]")
         check(lib.sparch_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                   ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0), ptr(w0),
                                   ptr(s0), theta, p_drop, seed, ptr(s_out), ptr(s16), ptr(u_save), ptr(w_save),
-                                  ptr(count), _stream()), "sparch_cell_fwd")
+                                  int(save16), ptr(count), _stream()), "sparch_cell_fwd")
         timer.stop(tok)
     else:
         if H % 4 != 0:
@@ -421,13 +433,12 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         rec0 = gemm_nn(s0, vmask)  # t = 0 drive: s0 is uniform noise, not binary (snns.py:559/702)
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
-        L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
         tok = timer.start(f"rec_cell_fwd[{kind}]")
         check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                       ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
                                       ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
-                                      ptr(s16), ptr(u_save), ptr(w_save), ptr(count), ptr(chan), nbytes,
-                                      ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
+                                      ptr(s16), ptr(u_save), ptr(w_save), int(save16), ptr(count), ptr(chan),
+                                      nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
         timer.stop(tok)
     return s_out, count, (u_save, w_save), s16
 
@@ -442,6 +453,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
     u_save, w_save = saved
+    save16 = u_save.dtype == torch.bfloat16
     dWx = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
     n_base = 6 if recurrent else 4
     ws = torch.empty(n_base + (2 if bn is not None else 0), Bp, H, dtype=torch.float32, device=dev)
@@ -449,7 +461,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     grads = {}
     if not recurrent:
         tok = timer.start(f"cell_bwd[{kind}]")
-        check(lib.sparch_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
+        check(lib.sparch_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save), int(save16),
                                   ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(u0),
                                   ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx), ptr(ws), ptr(bn_x), ptr(bn_mean),
                                   ptr(bn_invstd), _stream()), "sparch_cell_bwd")
@@ -482,7 +494,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
             L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
             tok = timer.start(f"rec_cell_bwd[{kind}]")
             check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
-                                          ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
+                                          int(save16), ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
                                           ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
                                           ptr(s_prev), ptr(ws), ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(chan),
                                           nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_bwd")

@@ -36,12 +36,12 @@ def test_prototype_arity_matches_header():
 
 def test_host_only_entry_points():
     lib = _capi.lib
-    assert lib.sparch_abi_version() == 2
+    assert lib.sparch_abi_version() == 3
     assert _capi.strerror(0) == "ok" and "workspace" in _capi.strerror(-3)
     assert lib.sparch_fbank_frames(16000) == 98 and lib.sparch_fbank_frames(399) == 0
     assert lib.sparch_vpack_bytes(1024) == 1024 * 1024 * 6   # three bf16 planes per fp32 element
     assert lib.sparch_vpack_bytes(100) == 4 * 4 * 1024 * 6  # 4 column tiles x (4 waves x 1 k-group of 32)
-    assert lib.sparch_vpack_bytes(2048) == 0                 # V slice would not fit the register file
+    assert lib.sparch_vpack_bytes(2048) == 0                 # V slice would not fit the register file: step path
     assert lib.sparch_rec_chan_bytes(256, 250, 1024) == 250 * 8 * 32 * 32 * 8
     assert lib.sparch_gemm_tn_workspace_bytes(1024, 1024, 64000) == 16 * 1024 * 1024 * 4
     assert lib.sparch_bn_bwd_workspace_bytes(64000, 1024) == 2 * 250 * 1024 * 4
@@ -52,4 +52,4 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.sparch_gemm_nt(0, 4, 4, None, 4, None, 4, None, 4, None, None, None) == -1
     assert lib.sparch_readout_fwd(2, 3, 257, 1, None, None, 1, 1, 1, None, None) == -1  # C > 256
     assert lib.sparch_cell_fwd(2, 1, 1, 1, 4, 16, None, None, 16, None, None, None, 16, None, 16,
-                               1.0, 0.0, 0, 16, None, None, None, None, None) == -1  # kind RLIF on non-recurrent entry
+                               1.0, 0.0, 0, 16, None, None, None, 0, None, None) == -1  # kind RLIF on non-recurrent entry

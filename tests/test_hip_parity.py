@@ -293,6 +293,49 @@ def _run_cell(kind, Wx, p, u0, w0, s0, g_s):
     return s.detach().cpu(), Wxd.grad.cpu(), {k: v.grad.cpu() for k, v in pd.items()}
 
 
+@pytest.mark.parametrize("kind,Bp,T,H", [("adLIF", 6, 40, 64), ("LIF", 9, 33, 128), ("RadLIF", 40, 50, 256),
+                                         ("RLIF", 5, 33, 64)])
+def test_bf16_saved_states_keep_every_discrete_decision(kind, Bp, T, H, monkeypatch):
+    """SPARCH_SAVE_DTYPE=bf16 (BASELINE configs[4] is the bf16 long-sequence case): u and w are kept in bf16 for
+    the backward pass, rounded so that the spike and box-car decisions stay exactly the fp32 ones.  Stated
+    bars against the fp32-saved path on the same inputs: forward spikes identical (the saves are not read by
+    the forward); dWx and dV IDENTICAL bit for bit (they depend on the saved states only through those
+    decisions — flip rate 0); dalpha / dbeta / da / db within 2e-2 of max-abs (2^-9 relative rounding of the
+    u / w factors; measured 1e-3 .. 5e-3)."""
+    Fn = _Fn()
+    if kind in ("RLIF", "RadLIF"):
+        case = _dyadic_cell_case(kind, Bp, T, H, 31)
+    else:
+        Wx, p, u0, w0, s0, g_s = _dyadic_cell_case("RadLIF" if kind == "adLIF" else "RLIF", Bp, T, H, 31)
+        p = {k: v for k, v in p.items() if k != "V"}
+        case = (Wx, p, u0, w0, s0, g_s)
+
+    def run():
+        Wx, p, u0, w0, s0, g_s = case
+        pd = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+        Wxd = Wx.to(DEV).requires_grad_(True)
+        s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), pd.get("V"),
+                                   u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), None)
+        (s * g_s.to(DEV)).sum().backward()
+        Fn.check_status()
+        return s.detach().cpu(), Wxd.grad.cpu(), {k: v.grad.cpu() for k, v in pd.items()}
+
+    s_a, dwx_a, g_a = run()
+    monkeypatch.setattr(Fn, "SAVE_BF16", True)
+    s_b, dwx_b, g_b = run()
+    assert s_a.sum() > 0 and torch.equal(s_a, s_b)
+    assert torch.equal(dwx_a, dwx_b), float((dwx_a - dwx_b).abs().max())
+    worst = 0.0
+    for k in g_a:
+        if k == "V":
+            assert torch.equal(g_a[k], g_b[k])
+        else:
+            e = relmax(g_b[k].numpy(), g_a[k].numpy())
+            worst = max(worst, e)
+            assert e <= 2e-2, (k, e)
+    print(f"bf16 saved states, {kind}: worst neuron-parameter gradient deviation {worst:.2e} of max-abs")
+
+
 @pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
 def test_recurrent_step_path_equals_persistent_kernels(kind, monkeypatch):
     """The step path (one launch per time step, recurrent product between the steps on the exact split
