@@ -64,7 +64,10 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int RT = 32;       // rows per batch tile
 constexpr int CT = 32;       // columns per workgroup (= one k-group of its consumers)
 constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
-constexpr int RING = 4;      // depth of the backward hand-off ring (2 suffices, see header)
+#ifndef REC_RING
+#define REC_RING 4
+#endif
+constexpr int RING = REC_RING;  // depth of the backward hand-off ring (2 suffices, see header)
 constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 // Scope of the hand-off accesses.  Experiment hooks (diagnostic builds only); the shipped values are
 // agent scope / sc1, the only combination that is correct for any placement of the workgroups.
@@ -792,11 +795,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, (unsigned)(t % RING) * slot_bytes + tile_off, 0,
                                                        REC_ST_AUX);
             }
+#ifndef REC_NO_RESET
             if (t + 2 < T) {
                 const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
                 __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (unsigned)((t + 2) % RING) * slot_bytes + tile_off,
                                                        0, REC_ST_AUX);
             }
+#endif
         }
         PROF_STAMP(3);  // pointwise + tile store issue
 #ifndef REC_NO_PUBLISH_BARRIER

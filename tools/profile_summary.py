@@ -7,8 +7,13 @@
                  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (FETCH_SIZE counts wide
                  streaming reads at 1/2 on gfx950; both counters are in KiB).
 
+  MFMA busy    : one pass `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16`-style
+                 (counter names as the installed rocprofv3 lists them), kernel trace only:
+                 utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+
 usage: profile_summary.py stats  STATS_DIR  OUT.md OUT.csv  "title" STEPS
        profile_summary.py pmc    FETCH_DIR WRITE_DIR OUT.md OUT.json "title"
+       profile_summary.py mfma   PMC_DIR OUT.md "title"
 """
 import collections
 import csv
@@ -64,10 +69,40 @@ def pmc(fetch_dir, write_dir, out_md, out_json, title):
             o.write(f"| `{k}` | {v['launches']} | {v['fetch_kb']:.0f} | {v['write_kb']:.0f} | {v['hbm_bytes'] / 1e6:.0f} |\n")
 
 
+def mfma(d, out_md, title):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "Start_Timestamp" in r and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    rows = []
+    for k, c in acc.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+            continue
+        busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+        us = (sum(dur[k]) / len(dur[k]) / 1e3) if dur[k] else float("nan")
+        rows.append((busy * len(c["GRBM_GUI_ACTIVE"]), k, len(c["GRBM_GUI_ACTIVE"]), us, busy, busy / (gui / 8 * 1024) if gui else 0.0,
+                     (gui / 8 / (us * 1e3)) if us == us and us > 0 else float("nan")))
+    rows.sort(reverse=True)
+    with open(out_md, "w") as o:
+        o.write(f"# {title}\n# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); "
+                "clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS note)\n\n")
+        o.write("| kernel | launches | avg us (profiled) | MFMA busy cycles | MFMA pipe utilisation | effective clock GHz |\n"
+                "|---|---|---|---|---|---|\n")
+        for _, k, n, us, busy, util, clk in rows[:20]:
+            o.write(f"| `{k}` | {n} | {us:.0f} | {busy:.3g} | {100 * util:.1f} % | {clk:.2f} |\n")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]))
     elif sys.argv[1] == "pmc":
         pmc(*sys.argv[2:7])
+    elif sys.argv[1] == "mfma":
+        mfma(*sys.argv[2:5])
     else:
         sys.exit(__doc__)
