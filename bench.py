@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = the workload's batch per GPU, strong = that batch split over the GPUs")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm over the global batch")
+    ap.add_argument("--graph", choices=["on", "off"], default="off",
+                    help="replay the whole step as one captured HIP graph (sparch_amd.graph.GraphedTrainStep)")
     args = ap.parse_args()
     global WORKLOAD
     WORKLOAD = WORKLOADS[args.workload]
@@ -244,17 +246,28 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        step()
+    graphed = None
+    if args.graph == "on":
+        if w["neuron_type"] in ("RNN", "MLP", "LiGRU", "GRU"):
+            raise SystemExit("--graph on: spiking workloads only")
+        from sparch_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt, loss_fn, x, y, reducer=reducer,
+                                   front_end=(lambda a: Fn.fbank(a, num_mel_bins=C)) if audio else None,
+                                   warmup=max(1, args.warmup))
+        run_step = graphed.step
+    else:
+        run_step = step
+        for _ in range(args.warmup):
+            step()
     Fn.check_status(dev)
     Fn.timer.reset()
-    Fn.timer.enabled = True
+    Fn.timer.enabled = graphed is None  # HIP events per named call exist only for eagerly launched kernels
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,6 +275,20 @@ def main():
     Fn.timer.enabled = False
     totals = Fn.timer.collect()
     Fn.check_status(dev)
+    roof_note = None
+    if graphed is not None:
+        # per-kernel durations for the roofline object: the same kernels launched eagerly (a graph replay has no
+        # per-kernel HIP events), `steps` instrumented steps right after the timed region
+        graphed.close()
+        Fn.timer.reset()
+        Fn.timer.enabled = True
+        for _ in range(args.steps):
+            step()
+        Fn.timer.enabled = False
+        totals = Fn.timer.collect()
+        Fn.check_status(dev)
+        roof_note = (f"timed region = {args.steps} replays of the captured step; per-kernel durations from {args.steps} "
+                     "eagerly launched, HIP-event instrumented steps of the same kernels right after it")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -321,6 +348,7 @@ def main():
                                    f"pdrop={w['pdrop']}, B={B}/GPU {inp} ({origin})",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "sync_bn": bool(world > 1 and args.sync_bn),
+                       "launch": "one captured HIP graph per step" if args.graph == "on" else "eager",
                        "grad_allreduce": (None if reducer is None else
                                           ("overlapped with backward" if reducer.overlap else "one collective after backward"))},
             "roofline": roof, "cpu_baseline": cpu,
@@ -329,6 +357,8 @@ def main():
         }
         if note:
             line["note"] = note
+        if roof_note and roof is not None:
+            roof["timing"] = roof_note
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

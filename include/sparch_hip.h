@@ -28,6 +28,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define SPARCH_SEED_IN_MEMORY (1ull << 63)
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -190,6 +192,8 @@ int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const fl
  *   spike_count (H*dirs) uint32: number of spikes surviving dropout per output feature;
  *           firing rate = count * keep_scale / (B*T)  (snns.py:174 after 278).
  *   Dropout: keep iff hash(seed, output element index) >= p; kept values scale by 1/(1-p).
+ *   `seed` (every entry point that takes one): the 63-bit seed itself, or SPARCH_SEED_IN_MEMORY | the device
+ *   address of a uint64 holding it — for a step captured in a HIP graph, whose arguments are frozen.
  * ---------------------------------------------------------------------------------- */
 
 /* Non-recurrent kinds (LIF, adLIF): one thread per (row, 4 columns), T-loop in registers. */
@@ -400,12 +404,15 @@ int sparch_gate_step(int mode, int B, int dirs, int T, int H, int t, const float
  * torch.optim.Adam's default path (see optim.hip).  `params`, `grads`, `exp_avg`, `exp_avg_sq` are HOST
  * arrays of n_tensors DEVICE pointers, `numel` a host array of element counts.
  * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t): formed by the caller in double precision.
+ * scalars_dev (nullable): device float[2] = {step_size, bc2_sqrt} read instead of the two arguments — for a
+ * step captured in a HIP graph, whose kernel arguments are frozen at capture time.
  * skip_if_nonzero (nullable): a device word, e.g. the recurrent kernels' status word — when it is non-zero
  * the step leaves parameters and moments untouched (a timed-out step must not be applied; no host sync). */
 int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                      float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
-                     float weight_decay, const uint32_t* skip_if_nonzero, void* stream);
+                     float weight_decay, const float* scalars_dev, const uint32_t* skip_if_nonzero,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,7 +96,7 @@ PROTOTYPES = {
     "sparch_ann_rec_step_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, c_uint64, P, P, P,
                                         P]),
     "sparch_gate_step": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, c_uint64, P]),
-    "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P, P]),
+    "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
 }
 
 

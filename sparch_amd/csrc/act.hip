@@ -25,8 +25,9 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(int kind, size_t n4, int H, const float* __restrict__ z,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   const float* __restrict__ dy, float p_drop, float inv_keep,
-                                                  uint64_t seed, float* __restrict__ out) {
+                                                  uint64_t seed_arg, float* __restrict__ out) {
     const bool drop = p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(seed_arg) : 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e0 = i * 4;
         const int h = (int)(e0 % (size_t)H);  // H % 4 == 0: the four elements share a row

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
     const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
     const size_t o_v = (size_t)bp * H + h;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const uint64_t seed = a.p_drop > 0.f ? resolve_seed(a.seed) : 0;
     const f32x4 yp = t > 0 ? ld4g(a.y_state + o_st - H) : zero;  // y_{t-1} (anns.py:452 / 584: zeros at t = 0)
 
     if constexpr (MODE == 0) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
             z[e] = sigm(xz[e] + rz[e]);                                   // anns.py:457
             c[e] = fmaxf(xc[e] + rc[e], 0.0f);                            // anns.py:458 (ReLU, line 388)
             y[e] = z[e] * yp[e] + (1.0f - z[e]) * c[e];                   // anns.py:459
-            const float k = a.p_drop > 0.f ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+            const float k = a.p_drop > 0.f ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
             yo[e] = y[e] * k;
         }
         st4g(a.y_state + o_st, y); st4g(a.z_save + o_st, z); st4g(a.c_save + o_st, c); st4g(a.y_out + o_out, yo);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
         for (int e = 0; e < 4; ++e) {
             c[e] = tanhf(xc[e] + rc[e]);                                  // anns.py:591 (Tanh, line 511)
             y[e] = z[e] * yp[e] + (1.0f - z[e]) * c[e];                   // anns.py:592
-            const float k = a.p_drop > 0.f ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+            const float k = a.p_drop > 0.f ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
             yo[e] = y[e] * k;
         }
         st4g(a.y_state + o_st, y); st4g(a.c_save + o_st, c); st4g(a.y_out + o_out, yo);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateArgs a) {
             const f32x4 cm = a.carry_mv ? ld4g(a.carry_mv + o_v) : zero, cd = a.carry_dir ? ld4g(a.carry_dir + o_v) : zero;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float k = a.p_drop > 0.f ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+                const float k = a.p_drop > 0.f ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
                 dy[e] = g[e] * k + cm[e] + cd[e];
             }
         }

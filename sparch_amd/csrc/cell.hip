@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
     if (ADAPT) ldv<VEC>(w, c.w0 + (size_t)bp * H + h);
     const bool has_norm = c.scale != nullptr;
     const bool drop = c.p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(c.seed) : 0;
 
     for (int t0 = 0; t0 < T; t0 += U) {
         float x[U][VEC];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
                 }
                 u[e] = al[e] * (u[e] - s[e]) + oma[e] * drive;           // snns.py:297 / 439
                 s[e] = (u[e] - c.theta) > 0.0f ? 1.0f : 0.0f;            // snns.py:29
-                const float k = drop ? keep_scale(c.seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+                const float k = drop ? keep_scale(seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
                 so[e] = s[e] * k;
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
     constexpr bool s16 = S16;  // compile-time: a run-time flag here breaks up the batched prefetch loads
     ld_saved<VEC>(u_t, c.u_save, ((size_t)bp * T + (T - 1)) * H + h, s16);
     const bool drop = c.p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(c.seed) : 0;
 
     for (int t0 = T - 1; t0 >= 0; t0 -= U) {
         float g[U][VEC], up[U][VEC], wp[U][VEC], xr[U][VEC];
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float k = drop ? keep_scale(c.seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+                const float k = drop ? keep_scale(seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
                 const float gs = (g[j][e] + gr[e]) * k;
                 float ds = gs - al[e] * du_n[e];
                 if (ADAPT) ds = ds + pb[e] * dw_n[e];

@@ -82,6 +82,15 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
+// The dropout seed of a launch is a kernel ARGUMENT by default.  For a step captured in a HIP graph the argument
+// is frozen at capture time, so the seed may instead live in device memory: bit 63 set = the low 63 bits are
+// the device address of a uint64 holding the seed (SPARCH_SEED_IN_MEMORY; the host advances that word between
+// replays).  Resolved once per thread at kernel entry.
+__device__ __forceinline__ uint64_t resolve_seed(uint64_t seed_or_address) {
+    if (seed_or_address & SPARCH_SEED_IN_MEMORY)
+        return *reinterpret_cast<const uint64_t*>(seed_or_address & ~SPARCH_SEED_IN_MEMORY);
+    return seed_or_address;
+}
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
     const uint32_t a = mix32((uint32_t)idx ^ (uint32_t)seed);
     const uint32_t b = mix32(a + (uint32_t)(idx >> 32) * 0x9E3779B9U + (uint32_t)(seed >> 32));

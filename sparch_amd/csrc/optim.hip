@@ -27,6 +27,7 @@ struct AdamBatch {
     int count;
     float step_size, beta1, beta2, bc2_sqrt, eps, weight_decay;
     const uint32_t* skip_if_nonzero;  // device word (nullable): non-zero -> the step is a no-op
+    const float* scalars;             // device {step_size, bc2_sqrt} (nullable): overrides the two arguments
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
@@ -42,6 +43,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
     float* __restrict__ m = a.m[ti];
     float* __restrict__ v = a.v[ti];
     const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
+    // a step captured in a HIP graph cannot take its per-step factors as (frozen) kernel arguments
+    const float step_size = a.scalars ? a.scalars[0] : a.step_size;
+    const float bc2_sqrt = a.scalars ? a.scalars[1] : a.bc2_sqrt;
 #pragma unroll 4
     for (int j = 0; j < ADAM_CHUNK / 256; ++j) {
         const long long i = base + (long long)j * 256 + threadIdx.x;
@@ -51,10 +55,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
         if (a.weight_decay != 0.0f) gi = gi + pi * a.weight_decay;
         const float mi = m[i] + (gi - m[i]) * w1;
         const float vi = v[i] * a.beta2 + (gi * gi) * w2;
-        const float d = sqrtf(vi) / a.bc2_sqrt + a.eps;
+        const float d = sqrtf(vi) / bc2_sqrt + a.eps;
         m[i] = mi;
         v[i] = vi;
-        p[i] = pi + (mi / d) * (-a.step_size);
+        p[i] = pi + (mi / d) * (-step_size);
     }
 }
 
@@ -63,11 +67,12 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
 extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                                 float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                                 float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
-                                float weight_decay, const uint32_t* skip_if_nonzero, void* stream) {
+                                float weight_decay, const float* scalars_dev, const uint32_t* skip_if_nonzero,
+                                void* stream) {
     SPARCH_ENTER();
     if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
         return SPARCH_EINVAL;
-    if (!(bc2_sqrt > 0.0f)) return SPARCH_EINVAL;
+    if (!scalars_dev && !(bc2_sqrt > 0.0f)) return SPARCH_EINVAL;
     for (int t = 0; t < n_tensors;) {  // ONE running index: empty tensors are skipped without being counted
         AdamBatch a{};
         a.count = 0;
@@ -85,7 +90,7 @@ extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float
         a.first_blk[a.count] = blk;
         if (a.count == 0) continue;
         a.step_size = step_size; a.beta1 = beta1; a.beta2 = beta2; a.bc2_sqrt = bc2_sqrt; a.eps = eps;
-        a.weight_decay = weight_decay; a.skip_if_nonzero = skip_if_nonzero;
+        a.weight_decay = weight_decay; a.skip_if_nonzero = skip_if_nonzero; a.scalars = scalars_dev;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, a);
         SPARCH_CHECK_LAUNCH();
     }

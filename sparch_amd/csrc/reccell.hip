@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 
     const bool has_norm = a.scale != nullptr;
     const bool drop = a.p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
     auto wx_ptr = [&](int t) {
         const int tt = d ? (T - 1 - t) : t;
         return a.Wx + ((size_t)b * T + tt) * H + colc;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             f32x4 so;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+                const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
                 so[e] = s[e] * k;
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
 
     const bool drop = a.p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
     auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp, f32x4& xr) {
         const int tt = d ? (T - 1 - t) : t;
         g = ld4(a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc);
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         const f32x4 al = pconst[0][pt], be = pconst[1][pt], pa = pconst[2][pt], pb = pconst[3][pt], gr = pconst[4][pt];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+            const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
             const float gs = (gv[e] + gr[e]) * k;
             float ds = gs - al[e] * du_n[e];
             if (ADAPT) ds = ds + pb[e] * dw_n[e];
@@ -955,6 +957,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
     const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
     const bool drop = a.p_drop > 0.0f;
+    const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // per-step operands of the pointwise rule: forward x = Wx[b, tt]; backward g = g_out[b, tt, d*H..],
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         f32x4 val, aux;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float k = drop ? keep_scale(a.seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+            const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
             if (!BWD) {
                 float xn = c0[e];
                 if (a.scale) xn = bn_affine(xn, sc[e], sh[e]);

@@ -36,6 +36,8 @@ FUSE_BN_SUMS = os.environ.get("SPARCH_FUSE_BN_SUMS", "1") != "0"
 # against the fp32 path (tests/test_hip_parity.py::test_bf16_saved_states_*).  Off by default.
 SAVE_BF16 = os.environ.get("SPARCH_SAVE_DTYPE", "fp32").lower() == "bf16"
 
+SEED_IN_MEMORY = 1 << 63  # include/sparch_hip.h SPARCH_SEED_IN_MEMORY: the seed argument carries a device address
+
 BN_MOMENTUM = 0.05  # snns.py:240
 # SyncBN for data-parallel runs (off by default = standard DDP semantics: per-rank statistics).
 # {"group": process group or None, "world": n}: BatchNorm then normalises with the statistics of the GLOBAL

@@ -33,8 +33,46 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError("sparch_amd.optim.Adam: amsgrad is not implemented (the reference does not use it)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
 
+    def enable_graph_mode(self):
+        """Keep the per-step factors (lr / (1 - beta1^t), sqrt(1 - beta2^t)) in DEVICE memory, computed by a few
+        captured torch ops from a device step counter, so that `step()` can be part of a HIP graph (kernel
+        arguments are frozen at capture time).  The arithmetic is the same double-precision formula the host
+        path evaluates; `lr` is read from a device scalar that `step()` refreshes whenever the scheduler changed
+        the group's value.  One parameter group stepping together (the reference's use)."""
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("sparch_amd.optim.Adam graph mode: one parameter group")
+        group = self.param_groups[0]
+        dev = group["params"][0].device
+        t0 = 0.0
+        for p in group["params"]:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            t0 = float(st["step"])
+        self._g = {"t": torch.full((), t0, dtype=torch.float64, device=dev),
+                   "lr": torch.full((), float(group["lr"]), dtype=torch.float64, device=dev),
+                   "lr_host": float(group["lr"]),
+                   "scalars": torch.zeros(2, dtype=torch.float32, device=dev)}
+
+    def sync_lr(self):
+        """Graph mode, outside the captured region: push a learning rate changed by the scheduler."""
+        g = getattr(self, "_g", None)
+        if g is not None and float(self.param_groups[0]["lr"]) != g["lr_host"]:
+            g["lr_host"] = float(self.param_groups[0]["lr"])
+            g["lr"].fill_(g["lr_host"])
+
+    def note_replay(self):
+        """Graph mode: a replay advanced the device step counter; keep the host-side `step` entries in step."""
+        for p in self.param_groups[0]["params"]:
+            if p in self.state:
+                self.state[p]["step"] += 1
+
     @torch.no_grad()
     def step(self, closure=None):
+        if getattr(self, "_g", None) is not None:
+            return self._step_graph_mode()
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -63,7 +101,20 @@ class Adam(torch.optim.Optimizer):
                 self._launch(sel, group["lr"] / bc1, beta1, beta2, math.sqrt(bc2), group["eps"], group["weight_decay"])
         return loss
 
-    def _launch(self, ps, step_size, beta1, beta2, bc2_sqrt, eps, weight_decay):
+    def _step_graph_mode(self):
+        group, g = self.param_groups[0], self._g
+        ps = [p for p in group["params"] if p.grad is not None]
+        beta1, beta2 = group["betas"]
+        g["t"].add_(1.0)
+        bc1 = 1.0 - torch.pow(torch.full_like(g["t"], beta1), g["t"])
+        bc2 = 1.0 - torch.pow(torch.full_like(g["t"], beta2), g["t"])
+        g["scalars"].copy_(torch.stack([g["lr"] / bc1, torch.sqrt(bc2)]).to(torch.float32))
+        if not torch.cuda.is_current_stream_capturing():
+            self.note_replay()
+        self._launch(ps, 0.0, beta1, beta2, 1.0, group["eps"], group["weight_decay"], scalars=g["scalars"])
+        return None
+
+    def _launch(self, ps, step_size, beta1, beta2, bc2_sqrt, eps, weight_decay, scalars=None):
         n = len(ps)
         arr = ctypes.c_void_p * n
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
@@ -79,5 +130,6 @@ class Adam(torch.optim.Optimizer):
         # step is a no-op on the device until check_status() has reported it and cleared the word
         skip = status_word(ps[0].device)
         check(lib.sparch_adam_step(n, a_p, a_g, a_m, a_v, a_n, float(step_size), float(beta1), float(beta2),
-                                   float(bc2_sqrt), float(eps), float(weight_decay), skip.data_ptr(), _stream()),
+                                   float(bc2_sqrt), float(eps), float(weight_decay),
+                                   scalars.data_ptr() if scalars is not None else None, skip.data_ptr(), _stream()),
               "sparch_adam_step")

@@ -147,10 +147,16 @@ class _SpikingLayer(nn.Module):
         """Counter-based seed for the in-kernel dropout mask: device generator seed (no sync)
         mixed with this layer's call count.  Masks differ from torch's by construction."""
         # getattr defaults: modules un-pickled from a checkpoint written by the reference have neither field
+        word = getattr(self, "_seed_word", None)
+        if word is not None:
+            # graph mode (sparch_amd.graph): the seed lives in device memory and is advanced by a captured op,
+            # the kernels get its address (a kernel argument would be frozen at capture time)
+            word.add_(1)
+            return Fn.SEED_IN_MEMORY | word.data_ptr()
         self._calls = getattr(self, "_calls", 0) + 1
         index = getattr(self, "_layer_index", 0)
         base = torch.cuda.initial_seed() if device.type == "cuda" else torch.initial_seed()
-        return (base * 0x9E3779B97F4A7C15 + (index + 1) * 0x100000001B3 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        return (base * 0x9E3779B97F4A7C15 + (index + 1) * 0x100000001B3 + self._calls) & 0x7FFFFFFFFFFFFFFF
 
     def _cell_params(self):
         p = {"alpha": self.alpha}
@@ -346,6 +352,37 @@ class SNN(nn.Module):
                 dropout=self.dropout, normalization=self.normalization, use_bias=self.use_bias))
         return layers
 
+    def draw_states(self, batch, device):
+        """Every layer's initial states for one forward, drawn from torch's global CPU generator in the
+        reference's order (per hidden layer u, [w], s; then the readout's u): a list with one (u0, w0, s0)
+        tuple per hidden layer and the readout's u0 tensor last."""
+        last = self.num_layers - 1
+        states = []
+        for i, layer in enumerate(self.snn):
+            if self.use_readout_layer and i == last:
+                states.append(_rand_to(batch, layer.hidden_size, device))
+            else:
+                states.append(layer._draw_states(batch * (2 if layer.bidirectional else 1), device))
+        return states
+
+    def draw_states_into(self, static_states, batch):
+        """The same draws (same generator, same order), copied straight from pinned host memory into existing
+        device tensors — the static inputs of a captured step (sparch_amd.graph)."""
+        def fill(dst):
+            dst.copy_(torch.rand(dst.shape[0], dst.shape[1], pin_memory=True), non_blocking=True)
+
+        last = self.num_layers - 1
+        for i, (layer, dst) in enumerate(zip(self.snn, static_states)):
+            if self.use_readout_layer and i == last:
+                fill(dst)
+            else:
+                u0, w0, s0 = dst
+                assert u0.shape[0] == batch * (2 if layer.bidirectional else 1)
+                fill(u0)
+                if w0 is not None:
+                    fill(w0)
+                fill(s0)
+
     def forward(self, x):
         if self.reshape:
             if x.ndim == 4:
@@ -359,12 +396,9 @@ class SNN(nn.Module):
         # the previous step, instead of stalling the queue between two layers (120 us bubbles per layer in
         # the round-2 kernel trace).
         last = self.num_layers - 1
-        states = []
-        for i, layer in enumerate(self.snn):
-            if self.use_readout_layer and i == last:
-                states.append(_rand_to(x.shape[0], layer.hidden_size, x.device))
-            else:
-                states.append(layer._draw_states(x.shape[0] * (2 if layer.bidirectional else 1), x.device))
+        states = getattr(self, "_static_states", None)  # graph mode: refilled by draw_states_into() per step
+        if states is None:
+            states = self.draw_states(x.shape[0], x.device)
         rates = []
         for i, layer in enumerate(self.snn):
             if self.use_readout_layer and i == last:

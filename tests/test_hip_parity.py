@@ -1454,3 +1454,58 @@ def test_gemm_shape_sweep_pipelined_and_general_paths():
         chk(Fn.gemm_tn(A_t.to(DEV), D1[:, :min(K, 260)].contiguous().to(DEV)),
             A_t.double().T @ D1[:, :min(K, 260)].double(),
             (A_t.abs().double().T @ D1[:, :min(K, 260)].abs().double()) * 2e-6 + 1e-6, "dense_tn")
+
+
+# ------------------------------------------------------------------ the training step as one HIP graph
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["adLIF", "RadLIF"])
+def test_graphed_train_step_matches_eager_steps(sp, kind):
+    """sparch_amd.graph.GraphedTrainStep (zero_grad -> forward -> CE -> backward -> Adam as ONE captured HIP
+    graph; dropout seeds, Adam's per-step factors and the random initial states come from device memory)
+    against the same steps run eagerly: same initial parameters, same CPU generator seed (so the same initial
+    states in the same order), pdrop = 0.  Non-recurrent net: parameters after 5 steps agree to fp32 rounding
+    (the device evaluates Adam's bias-correction powers itself); recurrent net: losses agree step by step while
+    the trajectories coincide (dyadic V is not kept by training, so only the first steps are compared)."""
+    from sparch_amd.graph import GraphedTrainStep
+    from sparch_amd.optim import Adam
+
+    B, T, C, sizes = 16, 25, 40, [64, 64, 20]
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+
+    def make():
+        torch.manual_seed(11)
+        net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.0).to(DEV).train()
+        return net, Adam(net.parameters(), 1e-2)
+
+    loss_fn = torch.nn.CrossEntropyLoss()
+    steps = 5
+    net_c, opt_c = make()
+    torch.manual_seed(77)
+    gs = GraphedTrainStep(net_c, opt_c, loss_fn, x, y, warmup=0)
+    losses_g = [float(gs.step()) for _ in range(steps)]
+    _Fn().check_status()
+    # eager twin: construction of the graphed step consumed two forwards' worth of draws from the CPU generator
+    # (the static state buffers, and the refill before capture; capture itself runs no kernel)
+    net_d, opt_d = make()
+    torch.manual_seed(77)
+    net_d.draw_states(B, torch.device(DEV))
+    net_d.draw_states(B, torch.device(DEV))
+    losses_d = []
+    for _ in range(steps):
+        opt_d.zero_grad(set_to_none=True)
+        out, rates = net_d(x)
+        loss = loss_fn(out, y)
+        loss.backward()
+        opt_d.step()
+        losses_d.append(float(loss.detach()))
+    _Fn().check_status()
+    assert float(opt_c.state[next(iter(net_c.parameters()))]["step"]) == steps
+    n_cmp = steps if kind == "adLIF" else 2
+    np.testing.assert_allclose(losses_g[:n_cmp], losses_d[:n_cmp], rtol=2e-4)
+    if kind == "adLIF":
+        for (k, pa), pb in zip(net_d.named_parameters(), net_c.parameters()):
+            assert relmax(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) <= 2e-4, k
+    assert losses_g[-1] < losses_g[0]
+    gs.close()
