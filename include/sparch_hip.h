@@ -387,6 +387,28 @@ int sparch_ann_rec_step_bwd(int act, int B, int dirs, int T, int H, int s, const
                             const float* y_state, const float* rec, float p_drop, uint64_t seed,
                             float* dpre, float* y_prev, float* dpre_step, void* stream);
 
+/* LiGRU cell (LiGRULayer._ligru_cell, anns.py:449-462) as persistent kernels (gatedcell.hip): hidden sizes that are
+ * multiples of 32 up to 1024; a workgroup owns 16 hidden units with its slices of BOTH recurrent matrices.
+ *   z = sigmoid(Wzx*scz+shz + y_{t-1} Vz^T), c = relu(Wx*sc+sh + y_{t-1} V^T), y = z y_{t-1} + (1-z) c.
+ * vpack = sparch_ligru_vpack(H, Vz, V, backward): the exact three-plane bf16 fragments of the slices.
+ * forward outputs: y_out (B,T,H*dirs) = dropout(y), y_state / z_save / c_save (Bp,T,H) in cell time order;
+ * backward outputs (Bp,T,H at the ORIGINAL time index): dz_all, dc_all = gradients w.r.t. the two normalised
+ * projections, yprev_all = y_{t-1} (dVz = dz_all^T yprev_all, dV = dc_all^T yprev_all); carry (Bp,H): scratch
+ * carried between chunked launches.  chan: sparch_ligru_chan_bytes(Bp, H) of scratch.                  */
+size_t sparch_ligru_vpack_bytes(int H, int backward);
+int sparch_ligru_vpack(int H, const float* Vz, const float* V, int backward, float* vpack, void* stream);
+size_t sparch_ligru_chan_bytes(int Bp, int H);
+int sparch_ligru_fwd(int B, int dirs, int T, int H, const float* Wx, const float* sc, const float* sh,
+                     const float* Wzx, const float* scz, const float* shz, const float* vpack,
+                     float p_drop, uint64_t seed, float* y_out, float* y_state, float* z_save,
+                     float* c_save, void* chan, size_t chan_bytes, uint32_t* status,
+                     int steps_per_launch, void* stream);
+int sparch_ligru_bwd(int B, int dirs, int T, int H, const float* g_out, const float* y_state,
+                     const float* z_save, const float* c_save, const float* vpack_b, float p_drop,
+                     uint64_t seed, float* dz_all, float* dc_all, float* yprev_all, float* carry,
+                     void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
+                     void* stream);
+
 /* Gate arithmetic of ONE time step of the gated baselines (LiGRULayer._ligru_cell anns.py:449-462,
  * GRULayer._gru_cell anns.py:581-595); the recurrent products between the phases are GEMM calls.  This
  * round these cells run launch-per-step (see annstep.hip).  mode: 0 LiGRU forward, 1 GRU forward gates

@@ -190,8 +190,14 @@ class RNNLayer(_RecurrentANNLayer):
 
 
 class LiGRULayer(_RecurrentANNLayer):
-    """anns.py:342-462: z = sigmoid(.), c = relu(.), y = z y + (1-z) c; launch-per-step this round."""
+    """anns.py:342-462: z = sigmoid(.), c = relu(.), y = z y + (1-z) c — persistent kernels (csrc/gatedcell.hip)
+    for hidden sizes that are multiples of 32 up to 1024, launch-per-step otherwise."""
     KIND, GATES, ACT = "LiGRU", ("", "z"), nn.ReLU
+    persistent_units_per_workgroup = 16  # a workgroup owns 16 hidden units (sparch_amd.dp sizes the grid with it)
+
+    @property
+    def uses_persistent_kernel(self):
+        return Fn.ligru_persistent_ok(self.hidden_size)
 
 
 class GRULayer(_RecurrentANNLayer):

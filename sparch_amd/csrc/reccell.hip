@@ -52,45 +52,9 @@
 //     path for shapes whose grid cannot be co-resident).
 #include "common.h"
 
+#include "rec_common.h"
+
 namespace {
-
-typedef unsigned long long u64;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-constexpr int RT = 32;       // rows per batch tile
-constexpr int CT = 32;       // columns per workgroup (= one k-group of its consumers)
-constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
-#ifndef REC_RING
-#define REC_RING 4
-#endif
-constexpr int RING = REC_RING;  // depth of the backward hand-off ring (2 suffices, see header)
-constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
-// Scope of the hand-off accesses.  Experiment hooks (diagnostic builds only); the shipped values are
-// agent scope / sc1, the only combination that is correct for any placement of the workgroups.
-#ifndef REC_LD_SCOPE
-#define REC_LD_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#endif
-#ifndef REC_ST_SCOPE
-#define REC_ST_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#endif
-#ifndef REC_LD_AUX
-#define REC_LD_AUX 16 /* sc1 */
-#endif
-#ifndef REC_ST_AUX
-#define REC_ST_AUX 16 /* sc1 */
-#endif
-#ifndef REC_AHEAD
-#define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
-#endif
-constexpr u64 TIMEOUT_TICKS = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
-// "not written yet" pattern of the backward / dense hand-off ring: a SIGNALLING NaN.  Arithmetic results are
-// never signalling (the hardware quiets every NaN it produces or propagates, IEEE mode), so no tile value
-// can equal it.
-constexpr unsigned SENTINEL = 0x7FA5A5A5u;
 
 struct RecArgs {
     int B, dirs, T, H, Bp;
@@ -140,145 +104,6 @@ __device__ u64 g_rec_prof[2][512][8];
 #define PROF_STAMP(i)
 #define PROF_FLUSH(which)
 #endif
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-// saved states (u, w) as fp32 or bf16 (element index i)
-__device__ __forceinline__ f32x4 ld4_saved(const float* base, size_t i, bool s16) {
-    if (!s16) return ld4(base + i);
-    const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(base) + i);
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32((unsigned short)(raw >> (16 * e)));
-    return v;
-}
-template <bool IS_U>
-__device__ __forceinline__ void st4_saved(float* base, size_t i, f32x4 v, bool s16, float theta) {
-    if (!s16) { st4(base + i, v); return; }
-    unsigned long long raw = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        raw |= (unsigned long long)(IS_U ? save_u16(v[e], theta) : f32_to_bf16_rne(v[e])) << (16 * e);
-    *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(base) + i) = raw;
-}
-
-// Workgroup barrier for LDS hand-offs inside the time loops.  __syncthreads() also carries workgroup-scope
-// release / acquire fences on GLOBAL memory, i.e. an `s_waitcnt vmcnt(0)`: every wave would wait for the
-// acknowledgement of its write-through hand-off stores (~2 k cycles) and of its bulk output stores at every
-// barrier.  The loops only exchange LDS data across these barriers (cross-workgroup data goes through sc1
-// accesses that need no fence), so: LDS operations retired, then the bare barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// `s_waitcnt vmcnt(0)` as the builtin (the compiler's wait-count pass sees it and clears its scoreboard, unlike
-// an asm statement).  Placed where every outstanding vector-memory operation is long complete anyway, it keeps
-// hipcc from inserting its own conservative vmcnt(0) at a later join — e.g. behind the hand-off stores, where
-// it would wait ~2 k cycles for their write-through acknowledgements.
-__device__ __forceinline__ void vm_settled() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-
-__device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot) {
-    __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *(volatile int*)abort_slot = 1;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                   c, 0, 0, 0);
-}
-
-// exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (round-to-nearest-even at each step)
-__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
-    const __bf16 h = (__bf16)x;
-    const float r1 = x - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    const __bf16 l = (__bf16)r2;
-    hi = __builtin_bit_cast(unsigned short, h);
-    mid = __builtin_bit_cast(unsigned short, m);
-    lo = __builtin_bit_cast(unsigned short, l);
-}
-
-// V (or V^T) slice -> registers: per k-group, 2 k16-steps x 3 planes of 8 bf16 (4 VGPRs) each
-template <int KGW, int NW>
-__device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4* __restrict__ vpack, int ct,
-                                            int nkg, int wave, int lane) {
-#pragma unroll
-    for (int kk = 0; kk < KGW; ++kk) {
-        const int kg = wave + NW * kk;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                vb[kk][ks][p] = vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane];
-    }
-}
-
-
-// Load this wave's k-groups of a row tile's fp32 hand-off tiles (fragment order) from ring slot `base`,
-// re-loading every 16-byte piece that still holds the sentinel until all have landed (bounded spin).
-// lane (row li, k-half hh) of k16-step ks needs k = 16*ks + 8*hh + 4q + 0..3 of producer tile kg:
-// piece (ks*2+q)*64 + lane of that tile -> each wave-load is 1 KiB contiguous.
-__device__ __forceinline__ bool piece_missing(const u32x4& v) { return v[0] == SENTINEL || v[3] == SENTINEL; }
-
-// issue the four 1 KiB wave-loads of ONE k-group
-template <int NW>
-__device__ __forceinline__ void issue_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg,
-                                           int n_ct) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            // padding k-groups (beyond H) read past the end of the buffer resource: the hardware returns
-            // zeros for out-of-range buffer loads — no branch, and zeros are never "missing"
-            const unsigned off = kg < n_ct ? base + (unsigned)kg * TILE_BYTES + (unsigned)((ks * 2 + q) * 1024)
-                                           : 0xFFFFFF00u;
-            g[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
-        }
-}
-
-// the four pieces of ONE k-group: wait for them (the others stay in flight), re-load what still reads as the
-// sentinel until it has landed (bounded spin).  Fast path: four compares and one wave-uniform branch.
-__device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base,
-                                            int* abort_slot) {
-    unsigned miss = 0;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) miss |= piece_missing(g[ks][q]) ? (1u << (ks * 2 + q)) : 0u;
-    if (__any(miss != 0)) {
-        // slow path.  Re-loads go to temporaries and are waited for right here (builtin wait: the compiler's
-        // scoreboard stays exact), then merged by select: the pending loads of the later k-groups are not
-        // touched, so the fast path keeps its precise vmcnt(N) waits after the join.
-        const u64 t_start = __builtin_amdgcn_s_memrealtime();
-        for (unsigned spins = 0;; ++spins) {
-            __builtin_amdgcn_s_sleep(1);
-            u32x4 tmp[2][2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    tmp[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * 2 + q) * 1024),
-                                                                      0, REC_LD_AUX);
-            vm_settled();
-            unsigned still = 0;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned bit = 1u << (ks * 2 + q);
-                    const bool m = (miss & bit) != 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) g[ks][q][e] = m ? tmp[ks][q][e] : g[ks][q][e];
-                    if (m && piece_missing(tmp[ks][q])) still |= bit;
-                }
-            miss = still;
-            if (!__any(miss != 0)) break;
-            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                *(volatile int*)abort_slot = 1;  // the status word is raised at the kernel's exit
-                break;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------ forward
 // NW waves per workgroup, each taking the k-groups kg = wave + NW*kk of the contraction (partial tiles

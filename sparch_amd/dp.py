@@ -46,7 +46,8 @@ def persistent_grid_fills_gpu(layers, rows_per_rank, cus=256):
         if rows_per_rank is None:
             return True
         rows = rows_per_rank * (2 if getattr(lay, "bidirectional", False) else 1)
-        n_rt, n_ct = -(-rows // 32), -(-int(lay.hidden_size) // 32)
+        per_wg = int(getattr(lay, "persistent_units_per_workgroup", 32))  # hidden units (columns) per workgroup
+        n_rt, n_ct = -(-rows // 32), -(-int(lay.hidden_size) // per_wg)
         if n_ct * min(n_rt, max(1, cus // n_ct)) > cus - RCCL_CU_RESERVE:
             return True
     return False

@@ -170,6 +170,12 @@ def rec_step_path(H):
     return H > REC_PERSISTENT_MAX_H or os.environ.get("SPARCH_REC_STEP_PATH", "0") == "1"
 
 
+def ligru_persistent_ok(H):
+    """The LiGRU persistent kernels (gatedcell.hip) take hidden sizes that are multiples of 32 up to 1024;
+    SPARCH_LIGRU_PERSISTENT=0 forces the launch-per-step path (comparison in tests)."""
+    return H % 32 == 0 and H <= 1024 and os.environ.get("SPARCH_LIGRU_PERSISTENT", "1") != "0"
+
+
 def _f32c(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
 
@@ -1020,16 +1026,31 @@ class GatedLayerFn(torch.autograd.Function):
             ins.update(Wrx=proj["r"]["z_in"], scr=proj["r"]["sc"], shr=proj["r"]["sh"])
         outs = {"y_state": y_state, "z_save": z_save, "r_save": r_save, "c_save": c_save, "ry": ry, "y_out": y_out}
         p_drop, seed = cfg["p_drop"], cfg["seed"]
-        tok = timer.start(f"gated_fwd[{kind}]")
-        for t in range(T):
-            rec = _gemm_small(y_state[:, t - 1, :], Vgate, nn=False) if t > 0 else None   # y_{t-1} [Vz;V]^T  (anns.py:457-458)
-            if kind == "LiGRU":
-                _gate_step(0, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
-            else:
-                _gate_step(1, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
-                recc = _gemm_small(ry, P["c"]["V"], nn=False) if t > 0 else None       # (r y_{t-1}) V^T  (anns.py:591)
-                _gate_step(2, B, dirs, T, H, t, dict(ins, rec=recc), outs, p_drop, seed)
-        timer.stop(tok)
+        persistent = kind == "LiGRU" and ligru_persistent_ok(H)
+        if persistent:
+            # the whole time loop in one persistent launch per row-tile group (gatedcell.hip)
+            vp = torch.empty(lib.sparch_ligru_vpack_bytes(H, 0) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_ligru_vpack(H, ptr(P["z"]["V"]), ptr(P["c"]["V"]), 0, ptr(vp), _stream()), "sparch_ligru_vpack")
+            nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            tok = timer.start("ligru_fwd")
+            check(lib.sparch_ligru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
+                                       ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]), ptr(vp),
+                                       p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(c_save), ptr(chan),
+                                       nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                  "sparch_ligru_fwd")
+            timer.stop(tok)
+        else:
+            tok = timer.start(f"gated_fwd[{kind}]")
+            for t in range(T):
+                rec = _gemm_small(y_state[:, t - 1, :], Vgate, nn=False) if t > 0 else None   # y_{t-1} [Vz;V]^T  (anns.py:457-458)
+                if kind == "LiGRU":
+                    _gate_step(0, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
+                else:
+                    _gate_step(1, B, dirs, T, H, t, dict(ins, rec=rec), outs, p_drop, seed)
+                    recc = _gemm_small(ry, P["c"]["V"], nn=False) if t > 0 else None       # (r y_{t-1}) V^T  (anns.py:591)
+                    _gate_step(2, B, dirs, T, H, t, dict(ins, rec=recc), outs, p_drop, seed)
+            timer.stop(tok)
         ctx.cfg, ctx.shape, ctx.mats = cfg, (B, T, K, H), mats
         ctx.nsaved = {m: proj[m]["nsaved"] for m in mats}
         ctx.needs_b = {m: P[m]["Wb"] is not None for m in mats}
@@ -1061,21 +1082,34 @@ class GatedLayerFn(torch.autograd.Function):
                 "dz_all": d_all["z"], "dc_all": d_all["c"], "dr_all": d_all.get("r"), "yprev_all": yprev_all,
                 "ry_all": ry_all}
         p_drop, seed = cfg["p_drop"], cfg["seed"]
-        carry_mv = carry_dir = None
-        tok = timer.start(f"gated_bwd[{kind}]")
-        for t in range(T - 1, -1, -1):
-            o = dict(outs, carry_dir_out=cdir[t & 1])
-            i = dict(ins, carry_mv=carry_mv, carry_dir=carry_dir)
-            if kind == "LiGRU":
-                _gate_step(3, B, dirs, T, H, t, i, o, p_drop, seed)
-            else:
-                _gate_step(4, B, dirs, T, H, t, i, o, p_drop, seed)
-                dry = _gemm_small(dcp, Pm["c"]["V"], nn=True)        # gradient of r * y_{t-1}
-                _gate_step(5, B, dirs, T, H, t, {"dry": dry}, o, p_drop, seed)
-            if t > 0:
-                carry_mv = _gemm_small(dgate, Vgate, nn=True)        # [dz_pre | d*_pre] [Vz; V*]
-                carry_dir = cdir[t & 1]
-        timer.stop(tok)
+        if kind == "LiGRU" and ligru_persistent_ok(H):
+            vpb = torch.empty(lib.sparch_ligru_vpack_bytes(H, 1) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_ligru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vpb), _stream()), "sparch_ligru_vpack")
+            nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            carry = new(Bp, H)
+            tok = timer.start("ligru_bwd")
+            check(lib.sparch_ligru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(c_save), ptr(vpb),
+                                       p_drop, seed, ptr(d_all["z"]), ptr(d_all["c"]), ptr(yprev_all), ptr(carry),
+                                       ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                  "sparch_ligru_bwd")
+            timer.stop(tok)
+        else:
+            carry_mv = carry_dir = None
+            tok = timer.start(f"gated_bwd[{kind}]")
+            for t in range(T - 1, -1, -1):
+                o = dict(outs, carry_dir_out=cdir[t & 1])
+                i = dict(ins, carry_mv=carry_mv, carry_dir=carry_dir)
+                if kind == "LiGRU":
+                    _gate_step(3, B, dirs, T, H, t, i, o, p_drop, seed)
+                else:
+                    _gate_step(4, B, dirs, T, H, t, i, o, p_drop, seed)
+                    dry = _gemm_small(dcp, Pm["c"]["V"], nn=True)        # gradient of r * y_{t-1}
+                    _gate_step(5, B, dirs, T, H, t, {"dry": dry}, o, p_drop, seed)
+                if t > 0:
+                    carry_mv = _gemm_small(dgate, Vgate, nn=True)        # [dz_pre | d*_pre] [Vz; V*]
+                    carry_dir = cdir[t & 1]
+            timer.stop(tok)
         flat = lambda a: a.view(Bp * T, H)  # noqa: E731
         dV = {"z": gemm_tn(flat(d_all["z"]), flat(yprev_all))}
         if kind == "GRU":

@@ -1410,6 +1410,45 @@ def test_gated_baseline_layers_vs_oracle(kind, bidir, norm):
         assert relmax(v.grad.cpu().numpy(), r) <= 2e-4, k
 
 
+@pytest.mark.parametrize("bidir,B,T,H", [(False, 40, 23, 128), (True, 36, 17, 256)])
+def test_ligru_persistent_kernels_vs_launch_per_step_and_chunked(bidir, B, T, H, monkeypatch):
+    """LiGRU on the persistent kernels (csrc/gatedcell.hip: 16 hidden units per workgroup, forward on the
+    32x32x16 MFMA with interleaved [z | c] columns, backward contracting the stacked [dz_pre | dc_pre] on the
+    16x16x32 MFMA) against the launch-per-step path (same arithmetic, different summation order: 1e-5 of
+    max-abs), and chunked / per-step launches of the persistent kernels against the whole-sequence launch
+    (bit for bit)."""
+    from sparch_amd.anns import LiGRULayer
+
+    C = 48
+    torch.manual_seed(31)
+    layer = LiGRULayer(C, H, B, dropout=0.0, normalization="batchnorm", use_bias=False, bidirectional=bidir).to(DEV).train()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(B, T, C, generator=g).to(DEV)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g).to(DEV)
+
+    def run(persistent, spl):
+        monkeypatch.setenv("SPARCH_LIGRU_PERSISTENT", "1" if persistent else "0")
+        monkeypatch.setenv("SPARCH_REC_STEPS_PER_LAUNCH", spl)
+        layer.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y = layer(xd)
+        (y * gy).sum().backward()
+        _Fn().check_status()
+        return y.detach().cpu(), xd.grad.cpu(), {k: v.grad.cpu().clone() for k, v in layer.named_parameters()}
+
+    y0, dx0, g0 = run(True, "")
+    y1, dx1, g1 = run(False, "")
+    assert float(y0.abs().max()) > 0
+    assert relmax(y0.numpy(), y1.numpy()) <= 1e-5 and relmax(dx0.numpy(), dx1.numpy()) <= 2e-5
+    for k in g0:
+        assert relmax(g0[k].numpy(), g1[k].numpy()) <= 5e-5, k
+    for spl in ("5", "1"):
+        y2, dx2, g2 = run(True, spl)
+        assert torch.equal(y2, y0) and torch.equal(dx2, dx0), spl
+        for k in g0:
+            assert torch.equal(g2[k], g0[k]), (spl, k)
+
+
 def test_gemm_shape_sweep_pipelined_and_general_paths():
     """Shape sweep across the split-GEMM variants (pipelined kernel with shifted edge tiles and a peeled K tail,
     general bounds-checked kernel, split-K counts that do not divide K, bf16 spike planes, odd leading sizes):
