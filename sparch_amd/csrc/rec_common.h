@@ -184,4 +184,26 @@ __device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rs
     }
 }
 
+// exact truncation split of one k-group's tile (2 k16-steps x 8 fp32 values per lane) into the three bf16
+// fragments per k16-step: P[ks][0..2] = t1, t2, t3 with x = t1 + t2 + t3 (v_perm for the packing, AND + SUB for
+// the residuals: ~5.5 VALU instructions per value)
+__device__ __forceinline__ void split_tile(const u32x4 (&g)[2][2], u32x4 (&P)[2][3]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const unsigned x0 = g[ks][q][2 * pr], x1 = g[ks][q][2 * pr + 1];
+                const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
+                const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
+                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                P[ks][0][2 * q + pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                P[ks][1][2 * q + pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                P[ks][2][2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            }
+}
+
 }  // namespace
