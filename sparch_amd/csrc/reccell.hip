@@ -54,9 +54,6 @@
 
 #include "rec_common.h"
 
-#ifndef REC_SWP
-#define REC_SWP 0  /* 1: backward splits k-group kk+1 inside the MFMAs of group kk (sched_group_barrier 1 MFMA : 8 VALU). Measured no gain (1.37 vs 1.34-1.39 ms per launch): with two waves per SIMD the partner wave's VALU already fills the MFMA shadows */
-#endif
 #ifndef REC_ACC_REGS
 #define REC_ACC_REGS 0  /* backward: parameter / BatchNorm partial sums in LDS (1: in registers — measured no faster: 1.37 vs 1.36 ms per launch) */
 #endif
@@ -512,52 +509,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // in the ISSUE of its loads once the memory pipeline is full, so the issue is spread out: two
             // k-groups ahead of the one being multiplied, the rest of the loads interleaved with the MFMAs
             // (the partner wave on the SIMD computes while this one is stuck issuing).
-#if REC_SWP
-            // Software pipeline over the k-groups: while the 12 MFMAs of group kk run, the SAME wave splits group
-            // kk+1 (already landed and checked) and group kk+2's loads are in flight.  The split is ~90 VALU
-            // instructions per group and an MFMA occupies the SIMD's issue port for 8 of its 32 cycles: issued
-            // back to back (split, then MFMAs) the two phases add up — ~6 k cycles of SIMD time per step for
-            // 3.1 k of MFMA; interleaved (one MFMA, then a few VALU, by sched_group_barrier) the split hides in
-            // the MFMAs' shadow.
-            constexpr int AHEAD = KGW < 2 ? KGW : 2;
-            u32x4 raw[KGW][2][2];
-#pragma unroll
-            for (int kk = 0; kk < AHEAD; ++kk) issue_tile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
-            PROF_STAMP(0);  // first tile load issue
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            u32x4 P[2][2][3];
-            settle_tile(raw[0], rsrc, base + (unsigned)wave * TILE_BYTES, &abort_flag[par]);
-            split_tile(raw[0], P[0]);
-#pragma unroll
-            for (int kk = 0; kk < KGW; ++kk) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + AHEAD < KGW) issue_tile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
-                if (kk + 1 < KGW)
-                    settle_tile(raw[kk + 1], rsrc, base + (unsigned)(wave + NW * (kk + 1)) * TILE_BYTES, &abort_flag[par]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < KGW) split_tile(raw[kk + 1], P[(kk + 1) & 1]);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const u32x4 vl = vlo[wave][kk][ks][lane];
-                    // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first (see below)
-                    acc = mfma_bf16(P[kk & 1][ks][1], vb[kk][ks][1], acc);  // t2*mid
-                    acc = mfma_bf16(P[kk & 1][ks][2], vb[kk][ks][0], acc);  // t3*hi
-                    acc = mfma_bf16(P[kk & 1][ks][0], vl, acc);             // t1*lo
-                    acc = mfma_bf16(P[kk & 1][ks][1], vb[kk][ks][0], acc);  // t2*hi
-                    acc = mfma_bf16(P[kk & 1][ks][0], vb[kk][ks][1], acc);  // t1*mid
-                    acc = mfma_bf16(P[kk & 1][ks][0], vb[kk][ks][0], acc);  // t1*hi
-                }
-                if (kk + 1 < KGW) {
-#pragma unroll
-                    for (int m = 0; m < 12; ++m) {  // 1 MFMA : 8 VALU, twelve times
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    }
-                }
-            }
-#else
+            // Tried on top (round 2, not kept): splitting group kk+1 INSIDE the MFMAs of group kk (software
+            // pipeline with sched_group_barrier 1 MFMA : 8 VALU, and hand-placed half-pairs between the MFMAs
+            // with scheduling barriers) — hipcc hoists the ~90 split instructions above the MFMAs in every block
+            // that ends in the next group's branch, and the launch time did not move (1.37 vs 1.34-1.39 ms).
+            // With the producers' data always ready (consuming step t+2's tiles, a timing experiment) the step is
+            // 9.7 k cycles against 10.2 k: the phase is throughput-, not hand-off-latency-bound — L2 port
+            // 3.7 k, and MFMA (3.1 k) + split VALU (2.8 k) add up on the SIMD instead of overlapping.
             constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;
             u32x4 raw[KGW][2][2];
 #pragma unroll
@@ -609,7 +567,6 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     }
                 }
             }
-#endif
             float* rd = red[wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
