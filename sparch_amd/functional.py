@@ -514,10 +514,9 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
             dV = gemm_tn(s_prev.view(Bp * T, H), dWx.view(Bp * T, H), zero_diag=True, spike_side=0, spike16=True)
         else:  # fp32-MFMA comparison path (tests)
             dV = gemm_tn(s_prev.view(Bp * T, H).float(), dWx.view(Bp * T, H), zero_diag=True)
-        if True:  # s_prev rows of cell step 0 are zero on both paths
-            for dd in range(dirs):
-                rows = slice(dd * B, (dd + 1) * B)
-                gemm_tn(s0[rows], dWx[rows, (T - 1) if dd else 0, :], zero_diag=True, out=dV)
+        for dd in range(dirs):  # s_prev rows of cell step 0 are zero on both paths: add the s0 term
+            rows = slice(dd * B, (dd + 1) * B)
+            gemm_tn(s0[rows], dWx[rows, (T - 1) if dd else 0, :], zero_diag=True, out=dV)
         grads["V"] = dV
     names = ["alpha"] + (["beta", "a", "b"] if adaptive else [])
     lims = [ALPHA_LIM] + ([BETA_LIM, A_LIM, B_LIM] if adaptive else [])

@@ -1548,3 +1548,51 @@ def test_graphed_train_step_matches_eager_steps(sp, kind):
             assert relmax(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) <= 2e-4, k
     assert losses_g[-1] < losses_g[0]
     gs.close()
+
+
+@pytest.mark.gpu
+def test_timeout_degrades_to_one_launch_per_step_and_guards_the_optimizer(sp, monkeypatch):
+    """After an in-kernel timeout (simulated by raising the status word, as a recurrent kernel would): the
+    optimizer step and the BatchNorm running statistics are no-ops ON THE DEVICE while the word is raised,
+    `check_status(on_timeout="degrade")` reports it once and switches this process to one launch per time step,
+    and a training step in that mode gives bit-identical results to the persistent launch."""
+    Fn = _Fn()
+    from sparch_amd.optim import Adam
+
+    B, T, C = 8, 20, 40
+    torch.manual_seed(5)
+    net = sp.SNN((B, None, C), [64, 64, 20], neuron_type="RadLIF", dropout=0.0).to(DEV).train()
+    opt = Adam(net.parameters(), 1e-2)
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, 20, (B,), generator=g).to(DEV)
+
+    def step(apply):
+        opt.zero_grad(set_to_none=True)
+        torch.manual_seed(9)
+        out, rates = net(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        if apply:
+            opt.step()
+        return out.detach().clone(), {k: v.grad.clone() for k, v in net.named_parameters()}
+
+    out_a, g_a = step(False)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    Fn.status_word(DEV)[0] = 1                      # "a wait timed out"
+    step(True)                                      # forward updates BN statistics, Adam steps: both must skip
+    torch.cuda.synchronize()
+    after = net.state_dict()
+    for k, v in before.items():
+        if "num_batches" not in k:
+            assert torch.equal(v, after[k]), k
+    monkeypatch.setattr(Fn, "_degraded", set())
+    assert Fn.check_status(DEV, on_timeout="degrade") is True
+    assert Fn.check_status(DEV, on_timeout="degrade") is False   # reported once, word cleared
+    assert Fn.rec_steps_per_launch(T) == 1
+    out_b, g_b = step(False)                        # one launch per time step now
+    assert torch.equal(out_a, out_b)
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+    step(True)
+    torch.cuda.synchronize()
+    assert not torch.equal(before["snn.0.W.weight"], net.state_dict()["snn.0.W.weight"])
