@@ -512,7 +512,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // Tried on top (round 2, not kept): splitting group kk+1 INSIDE the MFMAs of group kk (software
             // pipeline with sched_group_barrier 1 MFMA : 8 VALU, and hand-placed half-pairs between the MFMAs
             // with scheduling barriers) — hipcc hoists the ~90 split instructions above the MFMAs in every block
-            // that ends in the next group's branch, and the launch time did not move (1.37 vs 1.34-1.39 ms).
+            // that ends in the next group's branch, and the launch time did not move (1.37 vs 1.34-1.39 ms); pinned
+            // with one asm statement per MFMA + 5-6 split instructions (bit-exact, 255 VGPRs) it was 1.39-1.43 ms:
+            // the SIMD's issue port is NOT what bounds the phase.
             // With the producers' data always ready (consuming step t+2's tiles, a timing experiment) the step is
             // 9.7 k cycles against 10.2 k: the phase is throughput-, not hand-off-latency-bound — L2 port
             // 3.7 k, and MFMA (3.1 k) + split VALU (2.8 k) add up on the SIMD instead of overlapping.
