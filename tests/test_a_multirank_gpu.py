@@ -14,7 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_gradients_and_syncbn():
-    port = 29700 + os.getpid() % 200
+    import socket
+
+    with socket.socket() as sock:  # a port nobody is listening on right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",

@@ -108,7 +108,11 @@ def _dp_worker(rank, world, port, q, overlap=None):
 def test_grad_allreducer_gloo_world2(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + (7 if overlap is False else 0)
+    import socket
+
+    with socket.socket() as sock:  # a port nobody is listening on right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
