@@ -213,26 +213,36 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
         // bf16 saves: the raw words are fetched here and unpacked at their use, so that the U steps' loads stay
         // one batch (unpacking next to each load made hipcc wait for every load in turn: 2x the kernel time)
         [[maybe_unused]] unsigned long long upr[U], wpr[U];
+        if constexpr (S16 && VEC == 4) {
+            // branch-free batch (steps below 0 re-read step 0: in range, never used): with the per-step `if (t >= 0)`
+            // the 64-bit raw words crossed basic blocks and hipcc waited for every load in turn
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int t = t0 - j;
-            if (t >= 0) {
+            for (int j = 0; j < U; ++j) {
+                const int t = max(t0 - j, 0);
                 const int tt = d ? (T - 1 - t) : t;
                 ldv<VEC>(g[j], c.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + h);
                 if (bn) ldv<VEC>(xr[j], c.bn_x + ((size_t)b * T + tt) * H + h);
-                if constexpr (S16 && VEC == 4) {
-                    // unconditional raw fetch (row t-1, or row 0 again at t = 0 where u0 / w0 are read below): no
-                    // branch between the loads of a batch
-                    const size_t i = ((size_t)bp * T + (t > 0 ? t - 1 : 0)) * H + h;
-                    upr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.u_save) + i);
-                    if (ADAPT) wpr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.w_save) + i);
-                } else if (t > 0) {
-                    const size_t i = ((size_t)bp * T + (t - 1)) * H + h;
-                    ld_saved<VEC>(up[j], c.u_save, i, s16);
-                    if (ADAPT) ld_saved<VEC>(wp[j], c.w_save, i, s16);
-                } else {
-                    ldv<VEC>(up[j], c.u0 + (size_t)bp * H + h);
-                    if (ADAPT) ldv<VEC>(wp[j], c.w0 + (size_t)bp * H + h);
+                const size_t i = ((size_t)bp * T + (t > 0 ? t - 1 : 0)) * H + h;  // t = 0 reads u0 / w0 below
+                upr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.u_save) + i);
+                if (ADAPT) wpr[j] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(c.w_save) + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int t = t0 - j;
+                if (t >= 0) {
+                    const int tt = d ? (T - 1 - t) : t;
+                    ldv<VEC>(g[j], c.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + h);
+                    if (bn) ldv<VEC>(xr[j], c.bn_x + ((size_t)b * T + tt) * H + h);
+                    if (t > 0) {
+                        const size_t i = ((size_t)bp * T + (t - 1)) * H + h;
+                        ld_saved<VEC>(up[j], c.u_save, i, s16);
+                        if (ADAPT) ld_saved<VEC>(wp[j], c.w_save, i, s16);
+                    } else {
+                        ldv<VEC>(up[j], c.u0 + (size_t)bp * H + h);
+                        if (ADAPT) ldv<VEC>(wp[j], c.w0 + (size_t)bp * H + h);
+                    }
                 }
             }
         }
