@@ -206,4 +206,19 @@ __device__ __forceinline__ void split_tile(const u32x4 (&g)[2][2], u32x4 (&P)[2]
             }
 }
 
+// Host side: can `grid` workgroups of this kernel be resident at once?  (The persistent launches wait for each
+// other inside the kernel.)  Occupancy as the runtime computes it for this kernel's registers / LDS, times the CU
+// count; cached per kernel.  The in-kernel spins are bounded anyway — this keeps a foreseeable miss (fewer CUs
+// than assumed, a build with more registers) from costing a 2 s timeout before the per-step fallback takes over.
+template <auto Kernel>
+bool grid_is_co_resident(unsigned grid, int threads, int cus) {
+    static const int per_cu = [threads] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kernel, threads, 0) != hipSuccess) n = 1;
+        (void)hipGetLastError();
+        return n;
+    }();
+    return (long long)per_cu * cus >= (long long)grid;
+}
+
 }  // namespace

@@ -1016,6 +1016,21 @@ int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
     return SPARCH_OK;
 }
 
+template <bool BWD, bool ADAPT>
+bool rec_co_resident(int kgw, unsigned grid, int cus) {
+#define SP_RES(KB, NWB) \
+    return BWD ? grid_is_co_resident<rec_bwd_kernel<ADAPT, KB, NWB>>(grid, 64 * NWB, cus) \
+               : grid_is_co_resident<rec_fwd_kernel<ADAPT, KB, NWB>>(grid, 64 * NWB, cus);
+    switch (kgw) {
+        case 1: SP_RES(1, 4)
+        case 2: SP_RES(1, 8)
+        case 4: SP_RES(2, 8)
+        case 8: SP_RES(4, 8)
+        default: return false;
+    }
+#undef SP_RES
+}
+
 template <bool BWD>
 int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipStream_t st) {
     const bool adapt = kind == SPARCH_KIND_RADLIF;
@@ -1044,6 +1059,14 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     } else {
         rt_per_launch = cus / a.n_ct;  // one workgroup per CU must be co-resident
         if (rt_per_launch < 1) { L = 1; rt_per_launch = a.n_rt_total; }
+    }
+    if (L > 1) {  // ask the runtime's occupancy calculator instead of assuming one workgroup per CU fits
+        const unsigned g = (unsigned)(a.n_ct * min(rt_per_launch, a.n_rt_total));
+        const bool ok = adapt ? rec_co_resident<BWD, true>(kgw, g, cus) : rec_co_resident<BWD, false>(kgw, g, cus);
+        if (!ok) {
+            if (a.save16 && !BWD) return SPARCH_EINVAL;  // bf16 saves need the whole-sequence forward launch
+            L = 1; rt_per_launch = a.n_rt_total;
+        }
     }
     for (int rt0 = 0; rt0 < a.n_rt_total; rt0 += rt_per_launch) {
         a.rt_base = rt0;
