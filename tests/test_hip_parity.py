@@ -1596,3 +1596,85 @@ def test_timeout_degrades_to_one_launch_per_step_and_guards_the_optimizer(sp, mo
     step(True)
     torch.cuda.synchronize()
     assert not torch.equal(before["snn.0.W.weight"], net.state_dict()["snn.0.W.weight"])
+
+
+# ------------------------------------------------------------------ shape sweeps over the round-2 code paths
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H,bidir", [(3, 7, 32, False), (33, 11, 96, True), (70, 5, 160, False), (9, 6, 1024, True)])
+def test_ligru_persistent_shape_sweep(B, T, H, bidir, monkeypatch):
+    """Ragged batches (row tiles with padding rows, several row-tile groups), hidden sizes with partial k-group
+    coverage per wave, the largest supported size, both directions: persistent LiGRU == launch-per-step LiGRU."""
+    from sparch_amd.anns import LiGRULayer
+
+    C = 20
+    torch.manual_seed(B + H)
+    layer = LiGRULayer(C, H, B, dropout=0.0, normalization="layernorm", use_bias=True, bidirectional=bidir).to(DEV).train()
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, C, generator=g).to(DEV)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g).to(DEV)
+
+    def run(persistent):
+        monkeypatch.setenv("SPARCH_LIGRU_PERSISTENT", "1" if persistent else "0")
+        layer.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y = layer(xd)
+        (y * gy).sum().backward()
+        _Fn().check_status()
+        return y.detach().cpu(), xd.grad.cpu(), {k: v.grad.cpu().clone() for k, v in layer.named_parameters()}
+
+    y0, dx0, g0 = run(True)
+    y1, dx1, g1 = run(False)
+    assert relmax(y0.numpy(), y1.numpy()) <= 2e-5 and relmax(dx0.numpy(), dx1.numpy()) <= 5e-5
+    for k in g0:
+        assert relmax(g0[k].numpy(), g1[k].numpy()) <= 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,Bp,T,H", [("RadLIF", 3, 9, 36), ("RLIF", 70, 6, 100), ("RadLIF", 33, 5, 1028)])
+def test_recurrent_step_path_shape_sweep(kind, Bp, T, H, monkeypatch):
+    """The step path on hidden sizes that are not multiples of 32 (partial column tiles), ragged row tiles, and
+    just above the persistent kernels' limit, against the oracle (dyadic V: spikes bit-equal)."""
+    Wx, p, u0, w0, s0, g_s = _dyadic_cell_case(kind, Bp, T, H, 100 + H)
+    monkeypatch.setenv("SPARCH_REC_STEP_PATH", "1")
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Wxr = Wx.clone().requires_grad_(True)
+    ref = orc.spiking_cell(kind, Wxr, pr, u0, w0, s0)
+    (ref * g_s).sum().backward()
+    s, dwx, grads = _run_cell(kind, Wx, p, u0, w0, s0, g_s)
+    assert torch.equal(s, ref.detach())
+    assert relmax(dwx.numpy(), Wxr.grad.numpy()) <= 2e-4
+    for k in grads:
+        assert relmax(grads[k].numpy(), pr[k].grad.numpy()) <= 2e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,bidir", [("adLIF", True), ("RadLIF", True), ("RLIF", False)])
+def test_bf16_saved_states_whole_network(sp, kind, bidir, monkeypatch):
+    """SPARCH_SAVE_DTYPE=bf16 through whole networks (BatchNorm sums folded into the backward kernels, both
+    directions): output identical, every weight / V / norm gradient identical to the fp32-saved run, neuron
+    parameters within 2e-2."""
+    Fn = _Fn()
+    B, T, C = 10, 30, 40
+    torch.manual_seed(4)
+    net = sp.SNN((B, None, C), [64, 64, 20], neuron_type=kind, dropout=0.0, bidirectional=bidir).to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, 20, (B,), generator=g).to(DEV)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(6)
+        out, rates = net(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        Fn.check_status()
+        return out.detach().cpu(), {k: v.grad.cpu().clone() for k, v in net.named_parameters()}
+
+    out_a, g_a = run()
+    monkeypatch.setattr(Fn, "SAVE_BF16", True)
+    out_b, g_b = run()
+    assert torch.equal(out_a, out_b)
+    for k in g_a:
+        if k.split(".")[-1] in ("alpha", "beta", "a", "b") and not k.startswith("snn.2."):
+            assert relmax(g_b[k].numpy(), g_a[k].numpy()) <= 2e-2, k
+        else:
+            assert torch.equal(g_a[k], g_b[k]), k
