@@ -120,6 +120,20 @@ int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B
                     float* C, int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* Weight operands pre-split into their bf16 planes.  A spiking layer's W (H x K) is the B operand of its
+ * projection (snns.py:261, x W^T) and of backward's dx = dWx W; both kernels would re-convert the same
+ * tile of W in every workgroup that stages it (250 row tiles at B*T = 32000).  sparch_split3 writes the
+ * exact truncation split x = p0 + p1 + p2 once: planes[p*n + i], bf16 bit patterns, n % 8 == 0.  The _wp
+ * entries take B together with those planes (same layout and ldb; B_planes may be NULL) and return the
+ * same bits as sparch_gemm_spike16_nt / sparch_gemm6_nn: where the pipelined kernel applies (K % 32 == 0,
+ * ldb % 8 == 0, full tiles) it copies the planes into LDS, elsewhere it converts B as before.        */
+int sparch_split3(size_t n, const float* x, uint16_t* planes, void* stream);
+int sparch_gemm_spike16_nt_wp(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
+                              const float* B, const uint16_t* B_planes, int ldb, float* C, int ldc,
+                              const float* bias, float* colstat_ws, void* stream);
+int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, const float* B,
+                       const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream);
+
 /* First-layer input (snns.py:261 on the network input): SHD/SSC-style binned spike counts are small
  * integers, exactly representable in bf16, but the library cannot know that on the host.
  * sparch_flag_bf16_exact sets *flag (device uint32) to 1 iff every element of x is bf16-exact; the

@@ -47,6 +47,9 @@ PROTOTYPES = {
     "sparch_gemm6_nn_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P]),
     "sparch_gemm6_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm6_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
+    "sparch_split3": (c_int, [c_size_t, P, P, P]),
+    "sparch_gemm_spike16_nt_wp": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, P, c_int, P, c_int, P, P, P]),
+    "sparch_gemm6_nn_wp": (c_int, [c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, P]),
     "sparch_gemm6_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),
     "sparch_flag_bf16_exact": (c_int, [c_size_t, P, P, P]),
     "sparch_gemm_auto_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),

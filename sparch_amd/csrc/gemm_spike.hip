@@ -79,6 +79,10 @@ struct SArgs {
     // only known on the device, with no host round trip)
     const unsigned* gate; unsigned gate_want;
     int e_exact;  // spike operand conversion: 0 = (x != 0), 1 = x itself (caller guarantees bf16-exact values)
+    // BPRE kernels: the dense B operand pre-split into its three exact bf16 planes (sparch_split3): plane p at
+    // Bp + p * bp_stride (elements), same row layout and ldb as B.  Weight matrices are split ONCE per step
+    // instead of once per workgroup that stages them (250 M-tiles re-converted the same W tile).
+    const unsigned short* Bp; size_t bp_stride;
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -319,9 +323,10 @@ constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of 
 // phase, barrier — the matrix pipe was busy 47 % of the time: neither workgroup's latency chain was
 // short enough for two to cover each other.)
 // !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false>
 __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
     static_assert(!S16 || MODE != 2, "a bf16 plane is a spike operand");
+    static_assert(!BPRE || (FAST && MODE != 1), "pre-split B: pipelined kernel, B is the dense operand");
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
@@ -366,7 +371,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr bool A16 = S16 && SPIKE_A, B16 = S16 && SPIKE_B;     // operand arrives as a bf16 plane
-    constexpr int NPA = BM * (A16 ? 4 : 8) / NT, NPB = BN * (B16 ? 4 : 8) / NT;  // 16-byte pieces per thread and tile
+    constexpr int NPB1 = BN * 4 / NT;  // 16-byte pieces per thread of ONE bf16 plane of the B tile
+    constexpr int NPA = BM * (A16 ? 4 : 8) / NT, NPB = BPRE ? 3 * NPB1 : BN * (B16 ? 4 : 8) / NT;  // pieces per thread and tile
     f32x4 ra[NPA], rb[NPB];
 
     // registers -> LDS stage at `st` (piece q of the NPA + NPB pieces a thread owns)
@@ -375,7 +381,9 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
         } else if (q < NPA + NPB) {
-            if constexpr (B16) store_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
+            if constexpr (BPRE)  // plane (q - NPA) / NPB1 straight into its LDS image: no conversion
+                store_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, st + A_PLANES * PLANE_A + ((q - NPA) / NPB1) * PLANE_B, tid);
+            else if constexpr (B16) store_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
             else store_piece<B_KM, BN, NT, SPIKE_B, true>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid, g.e_exact);
         }
     };
@@ -386,7 +394,10 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
                 load_piece16<A_KM, BM, NT>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
             else load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
         } else if (q < NPA + NPB) {
-            if constexpr (B16)
+            if constexpr (BPRE)
+                load_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, true, g.Bp + ((q - NPA) / NPB1) * g.bp_stride, g.ldb, n0,
+                                           g.N, k, k_end, 1, tid);
+            else if constexpr (B16)
                 load_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, reinterpret_cast<const unsigned short*>(g.B), g.ldb, n0, g.N, k, k_end, 1, tid);
             else load_piece<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
         }
@@ -515,6 +526,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             __syncthreads();
         }
         const int k_tail = k_begin + nt * BK;
+        if constexpr (!BPRE)   // (pre-split B: the host launches these kernels for K % 32 == 0 only)
         if (k_tail < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
             stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
             stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
@@ -650,12 +662,12 @@ bool fast_ok(const SArgs& g) {
            g.k_per_split >= 8 * BK;  // a short K range never fills the pipeline: general kernel, 2 workgroups per CU
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     const int wgs = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
-    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16>;
+    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
@@ -669,8 +681,52 @@ int launch(SArgs& g, int splits, hipStream_t st) {
     if (fast_ok<A_KM, B_KM, MODE, EPI, S16>(g)) return launch_variant<A_KM, B_KM, MODE, EPI, true, S16>(g, splits, st);
     return launch_variant<A_KM, B_KM, MODE, EPI, false, S16>(g, splits, st);
 }
+// the same with B's pre-split planes when the pipelined kernel applies (whole K tiles, 16-byte plane rows);
+// otherwise the ordinary kernels convert the fp32 B on the fly — same truncation split, identical results
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16 = false>
+int launch_wp(SArgs& g, int splits, hipStream_t st) {
+    const bool planes_ok = g.Bp != nullptr && aligned16(g.Bp) && g.ldb % 8 == 0 && (g.bp_stride % 8) == 0 &&
+                           g.k_per_split % BK == 0 && g.K % BK == 0 && (!B_KM || g.N % 8 == 0);
+    if (planes_ok && fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
+        return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, true>(g, splits, st);
+    return launch<A_KM, B_KM, MODE, EPI, S16>(g, splits, st);
+}
+
+// x -> three exact bf16 planes (truncation split, as store_piece<..., TRUNC> does on the fly)
+__global__ void split3_kernel(size_t n4, const u32x4* __restrict__ x, u32x2* __restrict__ p1, u32x2* __restrict__ p2,
+                              u32x2* __restrict__ p3) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const u32x4 v = x[i];
+    u32x2 w1, w2, w3;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const unsigned x0 = v[2 * pr], x1 = v[2 * pr + 1];
+        const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
+        const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
+        const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+        const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+        const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+        w1[pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        w2[pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+        w3[pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+    p1[i] = w1; p2[i] = w2; p3[i] = w3;
+}
 
 }  // namespace
+
+extern "C" int sparch_split3(size_t n, const float* x, uint16_t* planes, void* stream) {
+    SPARCH_ENTER();
+    if (n == 0 || n % 8 != 0 || !x || !planes) return SPARCH_EINVAL;
+    if (!aligned16(x) || !aligned16(planes)) return SPARCH_EALIGN;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n4,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<u32x2*>(planes),
+                       reinterpret_cast<u32x2*>(planes + n), reinterpret_cast<u32x2*>(planes + 2 * n));
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
 
 extern "C" int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int lda, float scale, const float* B,
                                     int ldb, float* C, int ldc, const float* bias, float* colstat_ws,
@@ -732,6 +788,37 @@ extern "C" int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk
     if (colstat_ws) return launch<false, false, 0, EPI_BIAS | EPI_STATS, true>(g, 1, st);
     if (bias) return launch<false, false, 0, EPI_BIAS, true>(g, 1, st);
     return launch<false, false, 0, EPI_NONE, true>(g, 1, st);
+}
+
+extern "C" int sparch_gemm_spike16_nt_wp(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
+                                         const float* B, const uint16_t* B_planes, int ldb, float* C, int ldc,
+                                         const float* bias, float* colstat_ws, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A_spk16 || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = reinterpret_cast<const float*>(A_spk16); g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
+    g.Bp = B_planes; g.bp_stride = (size_t)N * ldb;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = scale;
+    g.a_vec = aligned16(A_spk16) && (lda % 8 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (colstat_ws) return launch_wp<false, false, 0, EPI_BIAS | EPI_STATS, true>(g, 1, st);
+    if (bias) return launch_wp<false, false, 0, EPI_BIAS, true>(g, 1, st);
+    return launch_wp<false, false, 0, EPI_NONE, true>(g, 1, st);
+}
+
+extern "C" int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, const float* B,
+                                  const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = A; g.B = B; g.C = C; g.Bp = B_planes; g.bp_stride = (size_t)K * ldb;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    return launch_wp<false, true, 2, EPI_NONE>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const void* B, int ldb,

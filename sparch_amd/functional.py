@@ -21,6 +21,7 @@ from ._capi import KIND, check, lib, ptr
 USE_SPIKE_GEMM = os.environ.get("SPARCH_SPIKE_GEMM", "1") != "0"
 # spike operands travel between layers as bf16 0/1 planes next to the fp32 tensors (half the GEMM operand bytes)
 USE_SPIKE16 = os.environ.get("SPARCH_SPIKE16", "1") != "0"
+USE_PRESPLIT = os.environ.get("SPARCH_PRESPLIT", "1") != "0"  # weights split into bf16 planes once per step
 
 # Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
@@ -188,17 +189,34 @@ def flag_bf16_exact(x):
     return flag
 
 
-def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None, a16=None):
+def split_planes(W):
+    """The three exact bf16 planes of a weight matrix, (3, *W.shape) bf16 (W = p0 + p1 + p2 exactly, the
+    truncation split the GEMM kernels otherwise redo in every workgroup that stages a tile of W); None where
+    the pre-split kernels do not apply (SPARCH_PRESPLIT=0, or a layout they do not take)."""
+    if not USE_PRESPLIT or W.dtype != torch.float32 or not W.is_contiguous() or W.numel() % 8 or W.shape[-1] % 8:
+        return None
+    planes = torch.empty((3,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
+    check(lib.sparch_split3(W.numel(), ptr(W), ptr(planes), _stream()), "sparch_split3")
+    return planes
+
+
+def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None, a16=None, b_planes=None):
     """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials.
     spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path;
-    a16: the same spikes as a (M,K) bf16 0/1 plane (read instead of A)."""
+    a16: the same spikes as a (M,K) bf16 0/1 plane (read instead of A);
+    b_planes: split_planes(B) (same result; the kernel copies the planes instead of converting B)."""
     M, K = A.shape
     N = B.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
     ws = None
     if colstat:
         ws = torch.empty(2 * ((M + 127) // 128) * N, dtype=torch.float32, device=A.device)
-    if spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16:
+    if spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16 and b_planes is not None:
+        tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_spike16_nt_wp(M, N, K, ptr(a16), a16.stride(0), float(spike_scale), ptr(B),
+                                            ptr(b_planes), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream()),
+              "sparch_gemm_spike16_nt_wp")
+    elif spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16:
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike16_nt(M, N, K, ptr(a16), a16.stride(0), float(spike_scale), ptr(B), B.stride(0),
                                          ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike16_nt")
@@ -219,14 +237,18 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None,
     return C, ws
 
 
-def gemm_nn(A, B):
-    """A (M,K) @ B (K,N) -> (M,N)."""
+def gemm_nn(A, B, b_planes=None):
+    """A (M,K) @ B (K,N) -> (M,N).  b_planes: split_planes(B)."""
     M, K = A.shape
     N = B.shape[1]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    fn = lib.sparch_gemm6_nn if DENSE_GEMM == "split6" else lib.sparch_gemm_nn
     tok = timer.start(f"gemm_nn[{M}x{N}x{K}]")
-    check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()), "sparch_gemm_nn")
+    if b_planes is not None and DENSE_GEMM == "split6":
+        check(lib.sparch_gemm6_nn_wp(M, N, K, ptr(A), A.stride(0), ptr(B), ptr(b_planes), B.stride(0), ptr(C), N,
+                                     _stream()), "sparch_gemm6_nn_wp")
+    else:
+        fn = lib.sparch_gemm6_nn if DENSE_GEMM == "split6" else lib.sparch_gemm_nn
+        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()), "sparch_gemm_nn")
     timer.stop(tok)
     return C
 
@@ -549,8 +571,12 @@ class SpikingLayerFn(torch.autograd.Function):
         ctx.xflag = xflag
         x16 = cfg.get("in_spike16") if in_scale is not None else None
         x16 = x16.view(M, K) if x16 is not None else None
+        # the weights' bf16 planes, split once here and used by this projection and by backward's dx GEMM
+        need_dx = ctx.needs_input_grad[1]
+        w_planes = split_planes(W) if (x16 is not None or need_dx) and K % 32 == 0 and H >= 128 else None
+        ctx.w_planes = w_planes if need_dx else None
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale,
-                                  a_exact_flag=xflag, a16=x16)  # snns.py:261
+                                  a_exact_flag=xflag, a16=x16, b_planes=w_planes)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
@@ -606,7 +632,8 @@ class SpikingLayerFn(torch.autograd.Function):
         else:
             dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
-        dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
+        dx = gemm_nn(dx_raw, W, b_planes=ctx.w_planes).view(B, T, K) if ctx.needs_input_grad[1] else None
+        ctx.w_planes = None
         return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),
                 pg.get("V"), None, None, None)
 

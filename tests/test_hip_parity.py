@@ -167,6 +167,40 @@ def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
     assert bool(((acc.cpu().double() - ref2).abs() <= 2 * bound).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 1024), (640, 256, 512), (300, 136, 96), (512, 1024, 700),
+                                   (257, 70, 64), (2048, 520, 1000)])
+def test_gemm_presplit_weight_planes_are_bit_identical(M, N, K):
+    """sparch_split3 + the _wp GEMMs (weights split into bf16 planes once) against the kernels that convert
+    the fp32 weights on the fly: the planes sum back to W exactly and both products match bit for bit — on
+    shapes the pipelined plane kernel takes and on shapes where the _wp entries fall back."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    W = (torch.randn(N, K, generator=g) * torch.exp(4 * torch.randn(N, K, generator=g))).to(DEV)
+    planes = Fn.split_planes(W)
+    if K % 8:  # plane rows must be 16-byte loadable: no planes, the layers then convert on the fly
+        assert planes is None
+        return
+    assert planes.shape == (3, N, K)
+    p = planes.float()
+    assert torch.equal((p[0] + p[1]) + p[2], W) and torch.equal(p[0].view(torch.int32), W.view(torch.int32) & -65536)
+    a16 = (torch.rand(M, K, generator=g) < 0.15).to(torch.bfloat16).to(DEV)
+    A = a16.float()
+    bias = torch.randn(N, generator=g).to(DEV)
+    for colstat, b in ((True, bias), (False, bias), (False, None)):
+        C0, ws0 = Fn.gemm_nt(A, W, b, colstat=colstat, spike_scale=1.0, a16=a16)
+        C1, ws1 = Fn.gemm_nt(A, W, b, colstat=colstat, spike_scale=1.0, a16=a16, b_planes=planes)
+        assert torch.equal(C0, C1)
+        assert ws0 is None or torch.equal(ws0, ws1)
+    G = torch.randn(M, N, generator=g).to(DEV)  # dx = G W: W is the (K_gemm = N) x (N_gemm = K) operand
+    D0 = Fn.gemm_nn(G, W)
+    D1 = Fn.gemm_nn(G, W, b_planes=planes)
+    assert torch.equal(D0, D1)
+    # (heavy-tailed W: a few products dominate each sum, so the fp32 accumulation error sits nearer its
+    # worst case than on the gaussian operands of the tests above — bound 1e-5 of sum|a||b|)
+    ratio = (D1.double() - G.double() @ W.double()).abs() / (G.abs().double() @ W.abs().double() + 1e-6)
+    assert float(ratio.max()) <= 1e-5, float(ratio.max())
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_gemm_auto_device_gated_paths(exact):
     """Network-input GEMMs: the bf16-exactness flag is computed on the device and gates which of the two
