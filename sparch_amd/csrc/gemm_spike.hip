@@ -29,6 +29,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+#ifndef GEMM_TAIL2
+#define GEMM_TAIL2 2
+#endif
 constexpr int BK = 32;
 constexpr int KC_ROW = 40;    // bf16 per LDS row of a KC image (32 + 8 pad = 80 B)
 // bf16 per LDS row of a KM image of a ROWS-wide operand tile: ROWS + 32 pad (128 -> 320 B, 256 -> 576 B;
@@ -40,7 +43,7 @@ enum Epi { EPI_NONE = 0, EPI_BIAS = 1, EPI_STATS = 2 };
 
 // Diagnostic build only (-DSPARCH_REC_PROF): s_memtime stamps of the phases of one K-tile iteration
 #if defined(SPARCH_REC_PROF) && !defined(GA_NO_STAMPS)
-__device__ unsigned long long g_gemm_prof[8];
+__device__ unsigned long long g_gemm_prof[8 + 8 * 2];  // [8..]: per wave of the sampled workgroup: phase, barrier
 #define GP_DECL                                                                                  \
     unsigned long long gp_t = 0, gp_acc[5] = {0, 0, 0, 0, 0}, gp_c0, gp_r0;                      \
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(gp_c0), "=s"(gp_r0)::"memory");
@@ -54,6 +57,10 @@ __device__ unsigned long long g_gemm_prof[8];
         gp_t = now_;                                                                             \
     } while (0)
 #define GP_FLUSH()                                                                               \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 7) {                                            \
+        atomicAdd(&g_gemm_prof[8 + 2 * (threadIdx.x >> 6)], gp_acc[3]);                          \
+        atomicAdd(&g_gemm_prof[9 + 2 * (threadIdx.x >> 6)], gp_acc[4]);                          \
+    }                                                                                            \
     if (threadIdx.x == 0 && blockIdx.x == 7) {                                                   \
         unsigned long long c1_, r1_;                                                             \
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1_), "=s"(r1_)::"memory"); \
@@ -373,10 +380,15 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     constexpr bool A16 = S16 && SPIKE_A, B16 = S16 && SPIKE_B;     // operand arrives as a bf16 plane
     constexpr int NPB1 = BN * 4 / NT;  // 16-byte pieces per thread of ONE bf16 plane of the B tile
     constexpr int NPA = BM * (A16 ? 4 : 8) / NT, NPB = BPRE ? 3 * NPB1 : BN * (B16 ? 4 : 8) / NT;  // pieces per thread and tile
+    // FAST: two register sets, tiles in flight two K tiles ahead of the MFMAs (a load issued in phase t is
+    // converted in phase t + 2; one phase of a 256 x 128 tile is ~0.8 us, less than a loaded HBM round trip)
+    // (not the 256 x 256 TN kernels: their phase is twice as long and they have no registers to spare)
+    constexpr bool AHEAD2 = FAST && !(A_KM && B_KM && MODE != 2);
     f32x4 ra[NPA], rb[NPB];
+    [[maybe_unused]] f32x4 ra2[AHEAD2 ? NPA : 1], rb2[AHEAD2 ? NPB : 1];
 
     // registers -> LDS stage at `st` (piece q of the NPA + NPB pieces a thread owns)
-    auto convert_piece = [&](int q, unsigned short* st) __attribute__((always_inline)) {
+    auto convert_piece = [&](auto& ra, auto& rb, int q, unsigned short* st) __attribute__((always_inline)) {
         if (q < NPA) {
             if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
@@ -388,7 +400,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         }
     };
     // global -> registers, full in-range tile at K offset k (FAST only)
-    auto fetch_piece = [&](int q, int k) __attribute__((always_inline)) {
+    auto fetch_piece = [&](auto& ra, auto& rb, int q, int k) __attribute__((always_inline)) {
         if (q < NPA) {
             if constexpr (A16)
                 load_piece16<A_KM, BM, NT>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
@@ -404,31 +416,74 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     };
 
     // The MFMA phase of one K tile held in the LDS stage `cur`.  Fragment reads run one group AHEAD of the
-    // MFMAs that use them.  `side(q)` is called once per piece q, spread evenly over the groups, in the
-    // same scheduling region as that group's MFMAs (FAST: convert piece q of the next tile and re-issue
-    // its load).  No branch inside: a branch is a basic-block boundary, and the compiler's waitcnt
-    // insertion drains every outstanding load at one.
-    auto mfma_phase = [&](const unsigned short* cur, auto side) __attribute__((always_inline)) {
-        const unsigned short* As = cur;
-        const unsigned short* Bs = cur + A_PLANES * PLANE_A;
+    // MFMAs that use them, and the fragments of a phase's FIRST group are already in registers when it
+    // starts (pre_read).  `side(q)` is called once per piece q, spread evenly over the groups, in the same
+    // scheduling region as that group's MFMAs (FAST: convert piece q of the next tile and re-issue its
+    // load).  No branch inside: a branch is a basic-block boundary, and the compiler's waitcnt insertion
+    // drains every outstanding load at one.
+    // HAS_NEXT (pipelined loop): the workgroup barrier that hands the other stage `nxt` over sits INSIDE the
+    // phase, before its last TAIL groups — by then every side piece is stored and every fragment of `cur`
+    // is read — and the next phase's first fragments are read from `nxt` right behind it, so the matrix
+    // pipe has those groups' MFMAs (both waves of the SIMD) to run while the reads are in flight.  With the
+    // barrier at the phase boundary all eight waves started each K tile on LDS latency: per-wave stamps
+    // showed the SIMDs done 1950 cycles after the barrier against 1536 cycles of MFMAs.
+    GP_DECL
+    constexpr int WS = SPIKE_A ? WI : WJ, WD = SPIKE_A ? WJ : WI;   // spike-side / dense-side tiles per wave
+    constexpr int SB = FAST ? 2 : 1;
+    [[maybe_unused]] u32x4 fa[MODE == 2 ? 2 : 1][MODE == 2 ? WI : 1][3], fb[MODE == 2 ? 2 : 1][MODE == 2 ? WJ : 1][3];
+    [[maybe_unused]] u32x4 fs[MODE != 2 ? SB : 1][MODE != 2 ? WS : 1], fd[2][MODE != 2 ? WD : 1];
+    // MODE 2: all fragments of a 16-deep k step, double buffered across the two steps
+    auto read_step = [&](const unsigned short* st, int ks) __attribute__((always_inline)) {
+        const unsigned short* As = st;
+        const unsigned short* Bs = st + A_PLANES * PLANE_A;
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                fb[ks][j][p] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
+    };
+    // MODE 0 / 1: dense fragments double buffered by group, spike fragments by k step (the general kernel's
+    // 2-workgroup register budget has no room for the second spike buffer: there the spike fragments are
+    // re-read in place at the k-step boundary)
+    auto read_spike = [&](const unsigned short* st, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WS; ++i) {
+            if constexpr (SPIKE_A) fs[ks % SB][i] = frag_read<A_KM, BM>(st, (wm * WI + i) * 32, lane, ks);
+            else fs[ks % SB][i] = frag_read<B_KM, BN>(st + A_PLANES * PLANE_A, (wn * WJ + i) * 32, lane, ks);
+        }
+    };
+    auto read_dense = [&](const unsigned short* st, int buf, int ks, int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WD; ++j) {
+            if constexpr (SPIKE_A)
+                fd[buf][j] = frag_read<B_KM, BN>(st + A_PLANES * PLANE_A + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
+            else fd[buf][j] = frag_read<A_KM, BM>(st + p * PLANE_A, (wm * WI + j) * 32, lane, ks);
+        }
+    };
+    // the fragments of a phase's first group, from the stage it will run on
+    auto pre_read = [&](const unsigned short* st) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) read_step(st, 0);
+        else { read_spike(st, 0); read_dense(st, 0, 0, 2); }
+    };
+    auto mfma_phase = [&](const unsigned short* cur, const unsigned short* nxt, auto has_next, auto side)
+                          __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        constexpr int NG = MODE == 2 ? 12 : 6;              // MFMA groups of WI x WJ per K tile
+        constexpr int TAIL = !HAS_NEXT ? 0 : (MODE == 2 ? GEMM_TAIL2 : 1);  // groups behind the barrier
+        constexpr int PPG = (NPA + NPB + NG - TAIL - 1) / (NG - TAIL);
+        auto handover = [&]() __attribute__((always_inline)) {
+            GP_STAMP(3);  // MFMA groups with the next tile's conversion and the loads after it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            GP_STAMP(4);  // barrier
+            pre_read(nxt);
+        };
         if constexpr (MODE == 2) {
-            // both operands dense: six cross terms per 16-deep k step; all fragments of a step are read at
-            // once and double buffered across the two steps; a group = one term (WI x WJ MFMAs)
-            u32x4 fa[2][WI][3], fb[2][WJ][3];
-            auto read_step = [&](int ks) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < WI; ++i)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
-#pragma unroll
-                for (int j = 0; j < WJ; ++j)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        fb[ks][j][p] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
-            };
-            read_step(0);
-            constexpr int PPG = (NPA + NPB + 11) / 12;
+            // both operands dense: six cross terms per 16-deep k step; a group = one term
             // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
             constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
             constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
@@ -436,9 +491,13 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
-                    if (ks == 0 && c == 0) read_step(1);
+                    const int gi = ks * 6 + c;
+                    if (gi == 0) read_step(cur, 1);
+                    if (HAS_NEXT && gi == NG - TAIL) handover();
+                    if (gi < NG - TAIL) {
 #pragma unroll
-                    for (int q = 0; q < PPG; ++q) side((ks * 6 + c) * PPG + q);
+                        for (int q = 0; q < PPG; ++q) side(gi * PPG + q);
+                    }
 #pragma unroll
                     for (int i = 0; i < WI; ++i)
 #pragma unroll
@@ -449,36 +508,16 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             }
         } else {
             // one spike-side plane, three dense-side planes: a group = one plane of one k step
-            // (WI x WJ MFMAs); dense fragments double buffered by group, spike fragments by k step
-            // (the general kernel's 2-workgroup register budget has no room for the second spike buffer:
-            // there the spike fragments are re-read in place at the k-step boundary)
-            constexpr int WS = SPIKE_A ? WI : WJ, WD = SPIKE_A ? WJ : WI;
-            constexpr int SB = FAST ? 2 : 1;
-            u32x4 fs[SB][WS], fd[2][WD];
-            auto read_spike = [&](int ks) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < WS; ++i) {
-                    if constexpr (SPIKE_A) fs[ks % SB][i] = frag_read<A_KM, BM>(As, (wm * WI + i) * 32, lane, ks);
-                    else                   fs[ks % SB][i] = frag_read<B_KM, BN>(Bs, (wn * WJ + i) * 32, lane, ks);
-                }
-            };
-            auto read_dense = [&](int buf, int ks, int p) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < WD; ++j) {
-                    if constexpr (SPIKE_A) fd[buf][j] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
-                    else                   fd[buf][j] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + j) * 32, lane, ks);
-                }
-            };
-            read_spike(0);
-            read_dense(0, 0, 2);
-            constexpr int PPG = (NPA + NPB + 5) / 6;
 #pragma unroll
             for (int gi = 0; gi < 6; ++gi) {
                 const int ks = gi / 3, p = 2 - gi % 3;  // smallest plane first
-                if (p > 0) read_dense((gi + 1) & 1, ks, p - 1);
-                else if (ks == 0) { if constexpr (SB == 2) read_spike(1); read_dense((gi + 1) & 1, 1, 2); }
+                if (p > 0) read_dense(cur, (gi + 1) & 1, ks, p - 1);
+                else if (ks == 0) { if constexpr (SB == 2) read_spike(cur, 1); read_dense(cur, (gi + 1) & 1, 1, 2); }
+                if (HAS_NEXT && gi == NG - TAIL) handover();
+                if (gi < NG - TAIL) {
 #pragma unroll
-                for (int q = 0; q < PPG; ++q) side(gi * PPG + q);
+                    for (int q = 0; q < PPG; ++q) side(gi * PPG + q);
+                }
 #pragma unroll
                 for (int i = 0; i < WI; ++i)
 #pragma unroll
@@ -486,43 +525,58 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
                         if constexpr (SPIKE_A) acc[i][j] = mfma_bf16(fs[ks % SB][i], fd[gi & 1][j], acc[i][j]);
                         else                   acc[i][j] = mfma_bf16(fd[gi & 1][i], fs[ks % SB][j], acc[i][j]);
                     }
-                if constexpr (SB == 1) { if (p == 0 && ks == 0) read_spike(1); }
+                if constexpr (SB == 1) { if (p == 0 && ks == 0) read_spike(cur, 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
+    constexpr std::true_type with_next{};
+    constexpr std::false_type last_tile{};
     auto no_side = [](int) __attribute__((always_inline)) {};
 
-    GP_DECL
     if constexpr (FAST) {
         const int nt = (k_end - k_begin) / BK;  // full tiles
         if (nt > 0) {
-            // prologue: tile 0 -> stage 0, tile 1 -> registers
+            // prologue: tile 0 -> stage 0 (through set 1), tile 1 -> set 2, tile 2 -> set 1
+            // (past the last tile: fetch the last tile again — in range, never used)
+            auto k_of = [&](int t) { return k_begin + min(t, nt - 1) * BK; };
 #pragma unroll
-            for (int q = 0; q < NPA + NPB; ++q) fetch_piece(q, k_begin);
-            const int k1 = nt > 1 ? k_begin + BK : k_begin;
+            for (int q = 0; q < NPA + NPB; ++q) fetch_piece(ra, rb, q, k_begin);
+            if constexpr (AHEAD2) {
 #pragma unroll
-            for (int q = 0; q < NPA + NPB; ++q) { convert_piece(q, lds); fetch_piece(q, k1); }
+                for (int q = 0; q < NPA + NPB; ++q) fetch_piece(ra2, rb2, q, k_of(1));
+            }
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) { convert_piece(ra, rb, q, lds); fetch_piece(ra, rb, q, k_of(AHEAD2 ? 2 : 1)); }
             __syncthreads();
-            for (int t = 0; t + 1 < nt; ++t) {
+            pre_read(lds);
+            // phase t: MFMAs of tile t from stage t & 1; tile t + 1 (set 2 for even t, set 1 for odd t)
+            // -> the other stage, and that set's loads re-issued for tile t + 3
+            auto phase = [&](auto& xa, auto& xb, int t) __attribute__((always_inline)) {
                 GP_STAMP(-1);
                 const unsigned short* cur = lds + (t & 1) * STAGE;
                 unsigned short* nxt = lds + ((t + 1) & 1) * STAGE;
-                // tile t+2 (after the last one: fetch the last tile again — in range, never used)
-                const int k2 = k_begin + min(t + 2, nt - 1) * BK;
-                mfma_phase(cur, [&](int q) __attribute__((always_inline)) {
+                const int k3 = k_of(t + (AHEAD2 ? 3 : 2));
+                mfma_phase(cur, nxt, with_next, [&](int q) __attribute__((always_inline)) {
 #if !(defined(SPARCH_REC_PROF) && defined(GA_NO_STORE))
-                    convert_piece(q, nxt);
+                    convert_piece(xa, xb, q, nxt);
 #endif
 #if !(defined(SPARCH_REC_PROF) && defined(GA_NO_GLOAD))
-                    fetch_piece(q, k2);
+                    fetch_piece(xa, xb, q, k3);
 #endif
                 });
-                GP_STAMP(3);  // MFMA phase with the next tile's conversion and the loads after it
-                __syncthreads();
-                GP_STAMP(4);  // barrier
+            };
+            if constexpr (AHEAD2) {
+                int t = 0;
+                for (; t + 2 < nt; t += 2) {
+                    phase(ra2, rb2, t);
+                    phase(ra, rb, t + 1);
+                }
+                if (t + 1 < nt) phase(ra2, rb2, t);
+            } else {  // one set: tile t + 1 converted while its loads for tile t + 2 are re-issued
+                for (int t = 0; t + 1 < nt; ++t) phase(ra, rb, t);
             }
-            mfma_phase(lds + ((nt - 1) & 1) * STAGE, no_side);
+            mfma_phase(lds + ((nt - 1) & 1) * STAGE, nullptr, last_tile, no_side);
             __syncthreads();
         }
         const int k_tail = k_begin + nt * BK;
@@ -531,9 +585,10 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
             stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
 #pragma unroll
-            for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
+            for (int q = 0; q < NPA + NPB; ++q) convert_piece(ra, rb, q, lds);
             __syncthreads();
-            mfma_phase(lds, no_side);
+            pre_read(lds);
+            mfma_phase(lds, nullptr, last_tile, no_side);
             __syncthreads();
         }
     } else {
@@ -541,13 +596,14 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid);
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
-            for (int q = 0; q < NPA + NPB; ++q) convert_piece(q, lds);
+            for (int q = 0; q < NPA + NPB; ++q) convert_piece(ra, rb, q, lds);
             __syncthreads();
             if (k0 + BK < k_end) {
                 stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid);
                 stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid);
             }
-            mfma_phase(lds, no_side);
+            pre_read(lds);
+            mfma_phase(lds, nullptr, last_tile, no_side);
             __syncthreads();
         }
     }
@@ -561,7 +617,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         csum[j] = 0.f; csq[j] = 0.f;
         const int col = n0 + (wn * WJ + j) * 32 + li;
         float bj = 0.f;
-        if constexpr (EPI & EPI_BIAS) bj = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+        if constexpr (EPI & EPI_BIAS) bj = (g.bias != nullptr && (FAST || col < g.N)) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
 #pragma unroll
@@ -569,7 +625,10 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
                 const int row = m0 + (wm * WI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[i][j][r] * g.scale;
                 if constexpr (EPI & EPI_BIAS) v = v + bj;
-                if (row < g.M && col < g.N) {
+                // FAST: the (shifted) tile lies inside C — no predicates, the 64 stores of a lane go out
+                // back to back (a predicated store is its own basic block, and hipcc then waits for the
+                // previous store's acknowledgement, vmcnt(0), in each one)
+                if (FAST || (row < g.M && col < g.N)) {
                     Cz[(size_t)row * g.ldc + col] = v;
                     if constexpr (EPI & EPI_STATS) { csum[j] += v; csq[j] += v * v; }
                 }
@@ -1040,7 +1099,7 @@ extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda,
 
 #if defined(SPARCH_REC_PROF) && !defined(GA_NO_STAMPS)
 extern "C" int sparch_gemm_prof_read(unsigned long long* host_out, int reset) {
-    static unsigned long long zero[8];
+    static unsigned long long zero[8 + 8 * 2];
     if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_prof), sizeof(zero)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;

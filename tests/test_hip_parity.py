@@ -580,6 +580,25 @@ def test_recurrent_one_step_ahead_vs_oracle_trajectory(kind, Bp, T, H, spl):
     assert (n0 + n1) <= 1e-4 * ref_s.size + 2
 
 
+@pytest.mark.parametrize("M,H", [(7, 64), (1001, 1024), (4099, 128), (32000, 1024), (5, 30)])
+def test_bn_backward_apply_in_place_any_row_count(M, H):
+    """sparch_bn_bwd_apply (dx written over dy, four rows per trip + a ragged tail, scalar kernel for
+    H % 4 != 0) against the batch-norm backward formula in fp64."""
+    from sparch_amd._capi import check, lib, ptr
+    g = torch.Generator().manual_seed(M + H)
+    dy, x = torch.randn(M, H, generator=g), torch.randn(M, H, generator=g) * 2 + 0.5
+    gamma = torch.rand(H, generator=g) + 0.5
+    mean, var = x.double().mean(0), x.double().var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    xh = (x.double() - mean) * invstd
+    dbeta, dgamma = dy.double().sum(0), (dy.double() * xh).sum(0)
+    ref = gamma.double() * invstd * (dy.double() - dbeta / M - xh * dgamma / M)
+    d = dy.to(DEV)
+    args = [t.float().to(DEV) for t in (x, mean, invstd, gamma, dgamma, dbeta)]
+    check(lib.sparch_bn_bwd_apply(M, H, ptr(d), *[ptr(t) for t in args], ptr(d), None), "sparch_bn_bwd_apply")
+    assert relmax(d.cpu().numpy(), ref.numpy()) <= 2e-5
+
+
 @pytest.mark.parametrize("norm", ["batchnorm", "layernorm"])
 def test_projection_and_normalisation_vs_oracle(norm):
     """G1+G2 alone (no spikes, no chaos): x@W^T (+bias) -> BatchNorm/LayerNorm vs torch CPU fp32."""
