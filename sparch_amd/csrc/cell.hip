@@ -318,143 +318,238 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
 
 // ------------------------------------------------------------------ readout cell
 // Readout layer (snns.py:815-825): u_t = alpha u_{t-1} + (1-alpha) x_t, out = sum_t softmax_c(u_t).
-// One wave per batch row, time in chunks of RT steps staged through LDS, and the lane's meaning changes
-// per phase so that nothing needs a cross-lane reduction:
-//   lane = class : the linear recurrence over t (one FMA per step), u_t -> LDS [t][class]
-//   lane = time  : softmax over the classes of "its" time step, sequentially over the C values in LDS
-//                  (rows are CS = C|1 floats apart: odd stride, conflict-free for lane = time)
-//   lane = class : out_c += p[t][c] in time order (the same summation order as the reference's loop)
-// (The first version kept lane = class throughout and paid two butterfly reductions through the LDS
-// crossbar per time step: 137 us forward / 194 us backward for 256 x 250 x 35.)
-constexpr int RT = 128;  // time steps per chunk
-constexpr int RU = 8;    // global loads in flight per lane in the recurrence phases
-// More than 64 classes: NW waves per batch row (lane -> thread index, wave barrier -> workgroup barrier).
-template <int NW>
+// One workgroup of 256 threads per batch row; a chunk of up to 256 time steps (the whole sequence for the
+// reference's shapes) is staged in LDS, and the thread's meaning changes per phase so that nothing needs a
+// cross-lane reduction:
+//   thread = element : the chunk's projection, one coalesced sweep with every load in flight at once -> LDS
+//   thread = class   : the linear recurrence over t (one FMA per step, in place: x_t -> u_t)
+//   thread = time    : softmax over the classes of "its" time step, sequentially over the C values in LDS
+//                      (rows are CS floats apart: odd stride, conflict-free for thread = time)
+//   thread = class   : out_c += p[t][c] in time order (the same summation order as the reference's loop)
+// History (256 x 250 x 35): class-per-lane throughout with two butterfly reductions per step 137 / 194 us
+// (forward / backward); one wave per row with these phases on 128-step chunks 65 / 103 us, of which most was
+// global-load round trips (8 loads in flight per lane) and then the 64-rows-per-wave softmax phase running on one
+// SIMD of the CU.
+constexpr int RO_NT = 256;           // threads per batch row (and the most time steps per chunk)
+constexpr int RO_LPT = 36;           // elements per thread and load batch of the staging sweep
+constexpr int RO_FWD_FLOATS = 15872; // LDS floats of the forward kernel (62 KiB)
+constexpr int RO_BWD_FLOATS = 39168; // of the backward kernel: three chunk images (153 KiB, dynamic)
+constexpr unsigned RO_OOB = 0xFFFFFFF0u;
+__host__ __device__ inline int ro_row_stride(int C) { return (C & 1) ? C + 2 : C + 1; }  // odd, > C: column C is a dump slot
+inline int ro_chunk_steps(int T, int C, int lds_floats) {
+    const int fit = lds_floats / ro_row_stride(C);
+    return T < RO_NT ? (T < fit ? T : fit) : (RO_NT < fit ? RO_NT : fit);
+}
+// workgroup barrier for the LDS hand-offs between the phases: LDS-only fences (no vmcnt(0): the u_save / dWx
+// stores of a phase stay in flight across it, which __syncthreads() would wait for)
 __device__ __forceinline__ void ro_barrier() {
-    if (NW == 1) __builtin_amdgcn_wave_barrier();
-    else __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ro_row(const float* base, size_t row_elems, size_t row) {
+    // a null base gives an empty resource: loads return 0, stores are dropped
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base + row * row_elems : nullptr), 0,
+                                             base ? (int)(row_elems * sizeof(float)) : 0, 0x00020000);
+}
+// bounds-checked fp32 accesses (the builtins move raw 32-bit words: bit casts, not conversions)
+__device__ __forceinline__ float ro_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void ro_store(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+// (time, class) of the linear element index idx = first + 256 k of a chunk, advanced without divisions
+struct RoCursor {
+    int t, c, dq, dr, C;
+    __device__ RoCursor(int first, int C_) : t(first / C_), c(first % C_), dq(RO_NT / C_), dr(RO_NT % C_), C(C_) {}
+    __device__ __forceinline__ void next() {
+        t += dq; c += dr;
+        if (c >= C) { c -= C; ++t; }
+    }
+};
+__device__ __forceinline__ float ro_softmax_row(float* row, int C) {  // in place; returns nothing useful
+    float m = row[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float e = expf(row[c] - m);
+        row[c] = e;
+        den += e;
+    }
+    return den;
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void readout_fwd_kernel(int B, int T, int C, const float* __restrict__ Wx,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift,
-                                                         const float* __restrict__ alpha,
-                                                         const float* __restrict__ u0, float* __restrict__ out,
-                                                         float* __restrict__ u_save) {
-    __shared__ float us[RT * (64 * NW + 1)];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(RO_NT) void readout_fwd_kernel(int B, int T, int C, int rows, const float* __restrict__ Wx,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ alpha,
+                                                            const float* __restrict__ u0, float* __restrict__ out,
+                                                            float* __restrict__ u_save) {
+    __shared__ float us[RO_FWD_FLOATS];
+    const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int CS = C | 1;
-    const bool act = lane < C;
-    const int cc = act ? lane : 0;
-    const float al = clampf(alpha[cc], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
-    const float sc = scale ? scale[cc] : 1.0f, sh = scale ? shift[cc] : 0.0f;
-    float u = u0[(size_t)b * C + cc], acc = 0.f;
-    const float* xr = Wx + (size_t)b * T * C + cc;
-    for (int c0 = 0; c0 < T; c0 += RT) {
-        const int len = min(RT, T - c0);
-        // lane = class: recurrence
-        for (int t0 = 0; t0 < len; t0 += RU) {
-            float x[RU];
+    const int CS = ro_row_stride(C);
+    const bool act = tid < C;
+    const bool wave_has_class = (tid & ~63) < C;  // wave-uniform: waves past the classes skip the class phases
+    const int cc = act ? tid : C;
+    const int cp = act ? tid : 0;
+    const float al = clampf(alpha[cp], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
+    const bool has_bn = scale != nullptr;
+    const float sc = has_bn ? scale[cp] : 1.0f, sh = has_bn ? shift[cp] : 0.0f;
+    float u = u0[(size_t)b * C + cp], acc = 0.f;
+    const __amdgpu_buffer_rsrc_t rx = ro_row(Wx, (size_t)T * C, b), ru = ro_row(u_save, (size_t)T * C, b);
+    for (int c0 = 0; c0 < T; c0 += rows) {
+        const int len = min(rows, T - c0), n = len * C;
+        // thread = element: the chunk's projection -> LDS
+        {
+            RoCursor cur(tid, C);
+            for (int base = 0; base < n; base += RO_NT * RO_LPT) {
+                float v[RO_LPT];
 #pragma unroll
-            for (int j = 0; j < RU; ++j) x[j] = (t0 + j < len) ? xr[(size_t)(c0 + t0 + j) * C] : 0.f;
+                for (int k = 0; k < RO_LPT; ++k) {
+                    const int idx = base + tid + RO_NT * k;
+                    v[k] = ro_load(rx, idx < n ? (unsigned)(((size_t)c0 * C + idx) * sizeof(float)) : RO_OOB);
+                }
 #pragma unroll
-            for (int j = 0; j < RU; ++j) {
-                if (t0 + j >= len) break;
-                float xn = x[j];
-                if (scale) xn = bn_affine(xn, sc, sh);
-                u = al * u + oma * xn;                                   // snns.py:822
-                if (act) {
-                    us[(t0 + j) * CS + cc] = u;
-                    if (u_save) u_save[((size_t)b * T + c0 + t0 + j) * C + cc] = u;
+                for (int k = 0; k < RO_LPT; ++k) {
+                    const int idx = base + tid + RO_NT * k;
+                    us[idx < n ? cur.t * CS + cur.c : C] = v[k];
+                    cur.next();
                 }
             }
         }
-        ro_barrier<NW>();
-        // lane = time: softmax over classes, in place
-        for (int tl = lane; tl < len; tl += 64 * NW) {
-            float* row = us + tl * CS;
-            float m = row[0];
-            for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
-            float den = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float e = expf(row[c] - m);
-                row[c] = e;
-                den += e;
+        ro_barrier();
+        // thread = class: recurrence, in place (x_t -> u_t).  Whole groups of 8 steps run without predicates on
+        // running LDS / row offsets (the step is a handful of instructions: its issue time is the phase);
+        // the ragged tail goes step by step.
+        if (wave_has_class) {
+            float* p = us + cc;                                                      // -> us[t][cc]
+            unsigned go = act ? (unsigned)(((size_t)c0 * C + tid) * sizeof(float)) : RO_OOB;  // -> u_save[c0 + t][tid]
+            const unsigned gstep = act ? (unsigned)(C * sizeof(float)) : 0u;
+            int t0 = 0;
+            for (; t0 + 8 <= len; t0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = p[j * CS];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xn = has_bn ? bn_affine(x[j], sc, sh) : x[j];
+                    u = al * u + oma * xn;                               // snns.py:822
+                    p[j * CS] = u;
+                    ro_store(u, ru, go + j * gstep);
+                }
+                p += 8 * CS;
+                go += 8 * gstep;
             }
+            for (; t0 < len; ++t0) {
+                const float x = *p;
+                const float xn = has_bn ? bn_affine(x, sc, sh) : x;
+                u = al * u + oma * xn;
+                *p = u;
+                ro_store(u, ru, go);
+                p += CS;
+                go += gstep;
+            }
+        }
+        ro_barrier();
+        // thread = time: softmax over classes, in place
+        for (int tl = tid; tl < len; tl += RO_NT) {
+            float* row = us + tl * CS;
+            const float den = ro_softmax_row(row, C);
             for (int c = 0; c < C; ++c) row[c] = row[c] / den;
         }
-        ro_barrier<NW>();
-        // lane = class: out += softmax(u_t) in time order                 // snns.py:823
-        if (act) {
-            for (int t0 = 0; t0 < len; t0 += RU) {  // reads first (independent), then the ordered adds
-                float pv[RU];
+        ro_barrier();
+        // thread = class: out += softmax(u_t) in time order             // snns.py:823
+        if (wave_has_class) {
+            const float* p = us + cc;
+            int t0 = 0;
+            for (; t0 + 8 <= len; t0 += 8) {
+                float pv[8];
 #pragma unroll
-                for (int j = 0; j < RU; ++j) pv[j] = (t0 + j < len) ? us[(t0 + j) * CS + cc] : 0.f;
+                for (int j = 0; j < 8; ++j) pv[j] = p[j * CS];
 #pragma unroll
-                for (int j = 0; j < RU; ++j)
-                    if (t0 + j < len) acc = acc + pv[j];
+                for (int j = 0; j < 8; ++j) acc = acc + pv[j];
+                p += 8 * CS;
             }
+            for (; t0 < len; ++t0, p += CS) acc = acc + *p;
         }
-        ro_barrier<NW>();
+        ro_barrier();
     }
     if (act) out[(size_t)b * C + cc] = acc;
 }
 
 // Backward of the above.  With p_t = softmax(u_t) and g = dL/dout:
-//   e_t = p_t * (g - <p_t, g>)            (lane = time; independent over t)
+//   e_t = p_t * (g - <p_t, g>)            (thread = time; independent over t)
 //   du_t = alpha du_{t+1} + e_t,  dWx_t = (1-alpha) du_t,  dalpha += du_t (u_{t-1} - u_t) / (1-alpha)
-//                                          (lane = class; reverse time)
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int C, const float* __restrict__ g_out,
-                                                         const float* __restrict__ u_save,
-                                                         const float* __restrict__ alpha,
-                                                         const float* __restrict__ u0, float* __restrict__ dWx,
-                                                         float* __restrict__ dalpha_ws,
-                                                         const float* __restrict__ bn_x,
-                                                         const float* __restrict__ bn_mean,
-                                                         const float* __restrict__ bn_invstd) {
-    __shared__ float us[RT * (64 * NW + 1)];
-    __shared__ float gs[64 * NW];
-    const int lane = threadIdx.x;
+//                                          (thread = class; reverse time)
+// Three chunk images in LDS: u (overwritten by e), u_{t-1} - u_t, and BatchNorm's xhat of the raw projection.
+extern __shared__ __attribute__((aligned(16))) float ro_dyn_lds[];
+__global__ __launch_bounds__(RO_NT) void readout_bwd_kernel(int B, int T, int C, int rows, const float* __restrict__ g_out,
+                                                            const float* __restrict__ u_save,
+                                                            const float* __restrict__ alpha,
+                                                            const float* __restrict__ u0, float* __restrict__ dWx,
+                                                            float* __restrict__ dalpha_ws,
+                                                            const float* __restrict__ bn_x,
+                                                            const float* __restrict__ bn_mean,
+                                                            const float* __restrict__ bn_invstd) {
+    __shared__ float gs[RO_NT];
+    const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int CS = C | 1;
-    const bool act = lane < C;
-    const int cc = act ? lane : 0;
-    const float al = clampf(alpha[cc], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
-    gs[lane] = act ? g_out[(size_t)b * C + cc] : 0.f;
-    const float* ur = u_save + (size_t)b * T * C + cc;
+    const int CS = ro_row_stride(C);
+    float* const ue = ro_dyn_lds;            // [rows][CS] u_t, then e_t
+    float* const dl = ue + rows * CS;        // [rows][CS] u_{t-1} - u_t
+    float* const xh = dl + rows * CS;        // [rows][CS] xhat_t
+    const bool act = tid < C;
+    const bool wave_has_class = (tid & ~63) < C;
+    const int cc = act ? tid : C;
+    const int cp = act ? tid : 0;
+    const float al = clampf(alpha[cp], SP_ALPHA_LO, SP_ALPHA_HI), oma = 1.0f - al;
+    gs[tid] = act ? g_out[(size_t)b * C + cp] : 0.f;
     float du = 0.f, acc = 0.f;
     // BatchNorm backward's column sums folded in (nullable): sum_t dWx and sum_t dWx*xhat per (row, class)
     const bool bn = bn_x != nullptr;
-    const float bn_mu = bn ? bn_mean[cc] : 0.f, bn_is = bn ? bn_invstd[cc] : 0.f;
-    const float* xr = bn ? bn_x + (size_t)b * T * C + cc : nullptr;
     float acc_dy = 0.f, acc_dyx = 0.f;
-    const int nchunk = (T + RT - 1) / RT;
+    const __amdgpu_buffer_rsrc_t ru = ro_row(u_save, (size_t)T * C, b), rb = ro_row(bn_x, (size_t)T * C, b),
+                                 rd = ro_row(dWx, (size_t)T * C, b), r0 = ro_row(u0, (size_t)C, b);
+    const int nchunk = (T + rows - 1) / rows;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
-        const int c0 = ch * RT, len = min(RT, T - c0);
-        // lane = class: u_t of the chunk -> LDS
-        for (int t0 = 0; t0 < len; t0 += RU) {
-            float x[RU];
+        const int c0 = ch * rows, len = min(rows, T - c0), n = len * C;
+        // thread = element: u_t, u_{t-1} - u_t (u_{-1} = u0) and xhat_t of the chunk -> LDS
+        {
+            RoCursor cur(tid, C);
+            constexpr int LPT = RO_LPT / 2;
+            for (int base = 0; base < n; base += RO_NT * LPT) {
+                float vu[LPT], vx[LPT];
+                unsigned vp[LPT], v0[LPT];
 #pragma unroll
-            for (int j = 0; j < RU; ++j) x[j] = (t0 + j < len) ? ur[(size_t)(c0 + t0 + j) * C] : 0.f;
+                for (int k = 0; k < LPT; ++k) {
+                    const int idx = base + tid + RO_NT * k;
+                    const bool in = idx < n;
+                    const size_t e = (size_t)c0 * C + idx;           // element of the batch row
+                    const bool first = in && e < (size_t)C;          // time step 0: the step before is u0
+                    vu[k] = ro_load(ru, in ? (unsigned)(e * sizeof(float)) : RO_OOB);
+                    vx[k] = ro_load(rb, in ? (unsigned)(e * sizeof(float)) : RO_OOB);
+                    vp[k] = __builtin_amdgcn_raw_buffer_load_b32(ru, (in && !first) ? (unsigned)((e - C) * sizeof(float)) : RO_OOB, 0, 0);
+                    v0[k] = __builtin_amdgcn_raw_buffer_load_b32(r0, first ? (unsigned)(e * sizeof(float)) : RO_OOB, 0, 0);
+                }
 #pragma unroll
-            for (int j = 0; j < RU; ++j)
-                if (t0 + j < len && act) us[(t0 + j) * CS + cc] = x[j];
-        }
-        ro_barrier<NW>();
-        // lane = time: e_t in place
-        for (int tl = lane; tl < len; tl += 64 * NW) {
-            float* row = us + tl * CS;
-            float m = row[0];
-            for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
-            float den = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float e = expf(row[c] - m);
-                row[c] = e;
-                den += e;
+                for (int k = 0; k < LPT; ++k) {
+                    const int idx = base + tid + RO_NT * k;
+                    const int at = idx < n ? cur.t * CS + cur.c : C;
+                    const int cl = idx < n ? cur.c : 0;
+                    ue[at] = vu[k];
+                    dl[at] = __uint_as_float(vp[k] | v0[k]) - vu[k];   // exactly one of the two loads was in range
+                    xh[at] = bn ? (vx[k] - bn_mean[cl]) * bn_invstd[cl] : 0.f;
+                    cur.next();
+                }
             }
+        }
+        ro_barrier();
+        // thread = time: e_t in place
+        for (int tl = tid; tl < len; tl += RO_NT) {
+            float* row = ue + tl * CS;
+            const float den = ro_softmax_row(row, C);
             float dot = 0.f;
             for (int c = 0; c < C; ++c) {
                 const float pc = row[c] / den;
@@ -463,33 +558,41 @@ __global__ __launch_bounds__(64 * NW) void readout_bwd_kernel(int B, int T, int 
             }
             for (int c = 0; c < C; ++c) row[c] = row[c] * (gs[c] - dot);
         }
-        ro_barrier<NW>();
-        // lane = class: reverse recurrence; u_{t-1} - u_t re-read from u_save (coalesced, prefetched)
-        for (int t0 = len - 1; t0 >= 0; t0 -= RU) {
-            float uc[RU + 1];  // uc[j] = u_{t0-j}, uc[RU] = u_{t0-RU}
+        ro_barrier();
+        // thread = class: reverse recurrence (groups of 8 steps without predicates, then the ragged rest)
+        if (wave_has_class) {
+            int at = (len - 1) * CS + cc;                                            // -> [t][cc] of the three images
+            unsigned go = act ? (unsigned)(((size_t)(c0 + len - 1) * C + tid) * sizeof(float)) : RO_OOB;  // -> dWx[c0 + t][tid]
+            const unsigned gstep = act ? (unsigned)(C * sizeof(float)) : 0u;
+            int left = len;
+            for (; left >= 8; left -= 8) {
+                float ev[8], dv[8], xv[8];
 #pragma unroll
-            for (int j = 0; j <= RU; ++j) {
-                const int t = c0 + t0 - j;
-                uc[j] = t >= 0 ? ur[(size_t)t * C] : (t == -1 ? u0[(size_t)b * C + cc] : 0.f);
+                for (int j = 0; j < 8; ++j) { ev[j] = ue[at - j * CS]; dv[j] = dl[at - j * CS]; xv[j] = xh[at - j * CS]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    du = al * du + ev[j];
+                    const float dwx = oma * du;
+                    ro_store(dwx, rd, go - j * gstep);
+                    acc = acc + du * dv[j];
+                    acc_dy = acc_dy + dwx;
+                    acc_dyx = acc_dyx + dwx * xv[j];
+                }
+                at -= 8 * CS;
+                go -= 8 * gstep;
             }
-            float ev[RU], xv[RU];
-#pragma unroll
-            for (int j = 0; j < RU; ++j) ev[j] = (t0 - j >= 0) ? us[(t0 - j) * CS + cc] : 0.f;
-#pragma unroll
-            for (int j = 0; j < RU; ++j) xv[j] = (bn && t0 - j >= 0) ? xr[(size_t)(c0 + t0 - j) * C] : 0.f;
-#pragma unroll
-            for (int j = 0; j < RU; ++j) {
-                const int tl = t0 - j;
-                if (tl < 0) break;
-                du = al * du + ev[j];
+            for (; left > 0; --left) {
+                du = al * du + ue[at];
                 const float dwx = oma * du;
-                if (act) dWx[((size_t)b * T + c0 + tl) * C + cc] = dwx;
-                acc += du * (uc[j + 1] - uc[j]);
-                acc_dy += dwx;
-                acc_dyx += dwx * ((xv[j] - bn_mu) * bn_is);
+                ro_store(dwx, rd, go);
+                acc = acc + du * dl[at];
+                acc_dy = acc_dy + dwx;
+                acc_dyx = acc_dyx + dwx * xh[at];
+                at -= CS;
+                go -= gstep;
             }
         }
-        ro_barrier<NW>();
+        ro_barrier();
     }
     if (act) {
         dalpha_ws[(size_t)b * C + cc] = acc / oma;
@@ -594,12 +697,8 @@ extern "C" int sparch_readout_fwd(int B, int T, int C, const float* Wx, const fl
     SPARCH_ENTER();
     if (B <= 0 || T <= 0 || C <= 0 || C > 256 || !Wx || !alpha || !u0 || !out) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
-    if (C > 128)     hipLaunchKernelGGL(readout_fwd_kernel<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
-                                        alpha, u0, out, u_save);
-    else if (C > 64) hipLaunchKernelGGL(readout_fwd_kernel<2>, dim3(B), dim3(128), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
-                                        alpha, u0, out, u_save);
-    else hipLaunchKernelGGL(readout_fwd_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, Wx, scale, shift,
-                       alpha, u0, out, u_save);
+    hipLaunchKernelGGL(readout_fwd_kernel, dim3(B), dim3(RO_NT), 0, (hipStream_t)stream, B, T, C,
+                       ro_chunk_steps(T, C, RO_FWD_FLOATS), Wx, scale, shift, alpha, u0, out, u_save);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
@@ -613,12 +712,14 @@ extern "C" int sparch_readout_bwd(int B, int T, int C, const float* g_out, const
     if (B <= 0 || T <= 0 || C <= 0 || C > 256 || !g_out || !u_save || !alpha || !u0 || !dWx || !dalpha_ws)
         return SPARCH_EINVAL;
     if (bn_x && (!bn_mean || !bn_invstd)) return SPARCH_EINVAL;
-    if (C > 128)     hipLaunchKernelGGL(readout_bwd_kernel<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                                        alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
-    else if (C > 64) hipLaunchKernelGGL(readout_bwd_kernel<2>, dim3(B), dim3(128), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                                        alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
-    else hipLaunchKernelGGL(readout_bwd_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, B, T, C, g_out, u_save,
-                       alpha, u0, dWx, dalpha_ws, bn_x, bn_mean, bn_invstd);
+    const int rows = ro_chunk_steps(T, C, RO_BWD_FLOATS / 3);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(readout_bwd_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)(RO_BWD_FLOATS * sizeof(float)));
+    if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3(B), dim3(RO_NT), (size_t)3 * rows * ro_row_stride(C) * sizeof(float),
+                       (hipStream_t)stream, B, T, C, rows, g_out, u_save, alpha, u0, dWx, dalpha_ws, bn_x, bn_mean,
+                       bn_invstd);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
