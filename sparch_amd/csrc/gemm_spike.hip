@@ -90,6 +90,7 @@ struct SArgs {
     // Bp + p * bp_stride (elements), same row layout and ldb as B.  Weight matrices are split ONCE per step
     // instead of once per workgroup that stages them (250 M-tiles re-converted the same W tile).
     const unsigned short* Bp; size_t bp_stride;
+    int n_splits;  // K ranges (the grid walks tiles x n_splits work items)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -350,14 +351,24 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     const int li = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (g.N + BN - 1) / BN;
-    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Renumber so
-    // that an XCD owns a CONTIGUOUS range of (split, tile_m, tile_n): tiles that share an operand panel
-    // then share one L2 instead of pulling the panel through all eight.
-    // (any grid size: XCD x receives ceil or floor of grid/8 workgroups, the first grid%8 XCDs one more)
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int per = gridDim.x >> 3, extra = gridDim.x & 7;
-    const int lin = xcd * per + min(xcd, extra) + idx;
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  An XCD owns a
+    // CONTIGUOUS range of (split, tile_m, tile_n): tiles that share an operand panel then share one L2 instead
+    // of pulling the panel through all eight.  (Any grid size: the first grid % 8 XCDs have one workgroup
+    // more, the first total % 8 ranges one tile more.)
+    // PERSISTENT launches (grid < tiles: one workgroup per CU): a workgroup walks its XCD's range with the
+    // stride of that XCD's workgroups — no dispatch gap and no wave start-up between its tiles (measured per
+    // workgroup of the NT product: 38 us of life, ~5 us to the next one's first instruction).
     const int tiles_all = tiles_n * ((g.M + BM - 1) / BM);
+    const int total = tiles_all * g.n_splits;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int wgs_here = (gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);
+    const int lin_end = (xcd + 1) * (total >> 3) + min(xcd + 1, total & 7);
+    // (the general kernels and the 256 x 256 TN kernels — long K ranges, one item per workgroup — have no
+    // registers to spare for a loop: theirs is a single trip at compile time)
+    constexpr bool WALKS = FAST && !(A_KM && B_KM && MODE != 2);
+    int lin = xcd * (total >> 3) + min(xcd, total & 7) + idx;
+    if (lin >= lin_end) return;
+    do {
     const int split = lin / tiles_all, tile = lin - split * tiles_all;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     // FAST (host guarantees M >= BM, N >= BN, 16-byte loadable rows): an edge tile is SHIFTED back inside
@@ -672,6 +683,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             }
         }
     }
+    __syncthreads();  // the next tile's staging overwrites this tile's statistics rows / last stage
+    } while (WALKS && (lin += wgs_here) < lin_end);  // tile loop
 }
 
 __global__ void splitk_reduce_kernel2(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
@@ -724,7 +737,13 @@ bool fast_ok(const SArgs& g) {
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
-    const int wgs = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
+    const int work = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
+    g.n_splits = splits;
+    // pipelined kernels (one workgroup per CU): more work items than CUs -> a persistent grid of one workgroup
+    // per CU walking them (SPARCH_GEMM_PERSISTENT=0: one workgroup per item)
+    static const bool persistent = [] { const char* e = getenv("SPARCH_GEMM_PERSISTENT"); return !e || atoi(e) != 0; }();
+    const int cus = target_wgs(1);
+    const int wgs = (FAST && !(A_KM && B_KM && MODE != 2) && persistent && work > cus) ? cus : work;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
     auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
