@@ -423,9 +423,33 @@ int sparch_ligru_bwd(int B, int dirs, int T, int H, const float* g_out, const fl
                      void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
                      void* stream);
 
+/* GRU cell (GRULayer._gru_cell, anns.py:581-595) as persistent kernels: the same machine with a second hand-off
+ * per step (the reset gate sits inside the candidate's recurrent term):
+ *   z = sigmoid(xz + y Vz^T), r = sigmoid(xr + y Vr^T), c = tanh(xc + (r y) V^T), y' = z y + (1 - z) c.
+ * Two fragment buffers per direction of time (sparch_gru_vpack_bytes(H, backward, which): which 0 = the gates'
+ * [Vz | Vr], 1 = the candidate's V), filled by one sparch_gru_vpack call.  forward outputs as the LiGRU plus
+ * r_save; backward outputs (Bp,T,H, original time index): dz_all, dr_all, dc_all, yprev_all = y_{t-1},
+ * ry_all = r y_{t-1} (dVz = dz_all^T yprev_all, dVr = dr_all^T yprev_all, dV = dc_all^T ry_all).  Every workgroup of
+ * a row tile must be resident at once (two hand-offs inside a step): SPARCH_EINVAL when H / 16 exceeds the CU
+ * count — callers then use the launch-per-step path (sparch_gate_step).  chan: sparch_gru_chan_bytes(Bp, H).  */
+size_t sparch_gru_vpack_bytes(int H, int backward, int which);
+int sparch_gru_vpack(int H, const float* Vz, const float* Vr, const float* V, int backward, float* vpack_gate,
+                     float* vpack_cand, void* stream);
+size_t sparch_gru_chan_bytes(int Bp, int H);
+int sparch_gru_fwd(int B, int dirs, int T, int H, const float* Wx, const float* sc, const float* sh,
+                   const float* Wzx, const float* scz, const float* shz, const float* Wrx, const float* scr,
+                   const float* shr, const float* vpack_gate, const float* vpack_cand, float p_drop,
+                   uint64_t seed, float* y_out, float* y_state, float* z_save, float* r_save, float* c_save,
+                   void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch, void* stream);
+int sparch_gru_bwd(int B, int dirs, int T, int H, const float* g_out, const float* y_state, const float* z_save,
+                   const float* r_save, const float* c_save, const float* vpack_gate_b,
+                   const float* vpack_cand_b, float p_drop, uint64_t seed, float* dz_all, float* dr_all,
+                   float* dc_all, float* yprev_all, float* ry_all, float* carry, void* chan, size_t chan_bytes,
+                   uint32_t* status, int steps_per_launch, void* stream);
+
 /* Gate arithmetic of ONE time step of the gated baselines (LiGRULayer._ligru_cell anns.py:449-462,
- * GRULayer._gru_cell anns.py:581-595); the recurrent products between the phases are GEMM calls.  This
- * round these cells run launch-per-step (see annstep.hip).  mode: 0 LiGRU forward, 1 GRU forward gates
+ * GRULayer._gru_cell anns.py:581-595); the recurrent products between the phases are GEMM calls: the
+ * launch-per-step path (annstep.hip) for hidden sizes the persistent kernels above do not take.  mode: 0 LiGRU forward, 1 GRU forward gates
  * (z, r, r*y), 2 GRU forward candidate + state, 3 LiGRU backward, 4 GRU backward (dy, dz_pre, dc_pre),
  * 5 GRU backward (dr_pre).  `in` / `out` are HOST arrays of 14 device pointers each (unused slots NULL):
  *   in : Wx sc sh Wzx scz shz Wrx scr shr rec g_out carry_mv carry_dir dry

@@ -6,9 +6,10 @@ constructor signatures, parameter names / shapes (state_dict keys) and the order
 construction (anns.py:57-131, 173-208, 255-293, 367-410, 490-538, 617-642).  The arithmetic of MLP layers
 and of the readout runs in libsparch_hip.so (projection GEMMs on the exact bf16 split, BatchNorm folded
 into the activation kernel, softmax-sum readout) and so does the RNN baseline's cell (the persistent dense
-recurrent kernel, csrc/reccell.hip); the gated baselines (LiGRU, GRU) run launch-per-step this round: a host
-loop over time with the recurrent products on the library's GEMMs and the gate arithmetic in
-`sparch_gate_step` (csrc/annstep.hip) — correct, not yet a performance path.  No CPU fallback anywhere.
+recurrent kernel, csrc/reccell.hip) and the gated baselines' cells (LiGRU, GRU: persistent kernels with 16 hidden
+units per workgroup, csrc/gatedcell.hip, for hidden sizes that are multiples of 32 up to 1024).  Other hidden
+sizes of the gated baselines run launch-per-step: a host loop over time with the recurrent products on the
+library's GEMMs and the gate arithmetic in `sparch_gate_step` (csrc/annstep.hip).  No CPU fallback anywhere.
 """
 import torch
 import torch.nn as nn
@@ -159,7 +160,7 @@ class _RecurrentANNLayer(_HiddenANNLayer):
         return dirs
 
     def forward(self, x):
-        """LiGRU / GRU (anns.py:412-447, 540-579): launch-per-step on the HIP kernels (functional.GatedLayerFn)."""
+        """LiGRU / GRU (anns.py:412-447, 540-579) on the HIP kernels (functional.GatedLayerFn)."""
         Fn._require_device(x, "input")
         dirs = self._rows(x)
         mats = {"": "c", "z": "z", "r": "r"}
@@ -201,8 +202,15 @@ class LiGRULayer(_RecurrentANNLayer):
 
 
 class GRULayer(_RecurrentANNLayer):
-    """anns.py:465-595: z, r = sigmoid(.), c = tanh(W x + V (r y)), y = z y + (1-z) c; launch-per-step this round."""
+    """anns.py:465-595: z, r = sigmoid(.), c = tanh(W x + V (r y)), y = z y + (1-z) c — persistent kernels with two
+    hand-offs per step (csrc/gatedcell.hip) for hidden sizes that are multiples of 32 up to 1024, launch-per-step
+    otherwise."""
     KIND, GATES, ACT = "GRU", ("", "z", "r"), nn.Tanh
+    persistent_units_per_workgroup = 16
+
+    @property
+    def uses_persistent_kernel(self):
+        return Fn.gru_persistent_ok(self.hidden_size)
 
 
 class ReadoutLayerANN(_ANNLayer):

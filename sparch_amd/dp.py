@@ -12,9 +12,9 @@ the last one lands, flattens the bucket.  Two launch policies:
 
   * overlap (models WITHOUT recurrent layers): the bucket's all-reduce is launched at once, async, and
     runs on RCCL's stream underneath the next (earlier) layer's backward;
-  * deferred (models whose layers run the PERSISTENT recurrent kernels — RLIF / RadLIF / RNN up to 1024
-    hidden units; keyed on the layers' `uses_persistent_kernel`, not on having a V matrix: LiGRU / GRU and
-    the large-H step path launch per time step and overlap like everything else — AND whose persistent grid
+  * deferred (models whose layers run the PERSISTENT recurrent kernels — RLIF / RadLIF / RNN / LiGRU / GRU up
+    to 1024 hidden units; keyed on the layers' `uses_persistent_kernel`, not on having a V matrix: the
+    large-H step path launches per time step and overlaps like everything else — AND whose persistent grid
     needs the whole GPU): ONE all-reduce of all buckets at the end of backward.  Those kernels' workgroups
     wait for each other and need one CU each: an RCCL kernel that holds a few CUs while it waits for a peer
     rank keeps a 256-workgroup grid from becoming co-resident, and a peer whose own persistent kernel got

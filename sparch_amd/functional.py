@@ -177,6 +177,17 @@ def ligru_persistent_ok(H):
     return H % 32 == 0 and H <= 1024 and os.environ.get("SPARCH_LIGRU_PERSISTENT", "1") != "0"
 
 
+def gru_persistent_ok(H):
+    """The GRU persistent kernels (gatedcell.hip): hidden sizes that are multiples of 32 up to 1024 whose H / 16
+    workgroups per row tile fit the GPU at once (two hand-offs inside a step: no per-step degenerate form, so a
+    device in degraded mode takes the launch-per-step path); SPARCH_GRU_PERSISTENT=0 forces that path."""
+    if H % 32 != 0 or H > 1024 or os.environ.get("SPARCH_GRU_PERSISTENT", "1") == "0":
+        return False
+    if _degraded and torch.cuda.is_available() and torch.cuda.current_device() in _degraded:
+        return False
+    return H // 16 <= lib.sparch_device_cus()
+
+
 def _f32c(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
 
@@ -1053,7 +1064,24 @@ class GatedLayerFn(torch.autograd.Function):
         outs = {"y_state": y_state, "z_save": z_save, "r_save": r_save, "c_save": c_save, "ry": ry, "y_out": y_out}
         p_drop, seed = cfg["p_drop"], cfg["seed"]
         persistent = kind == "LiGRU" and ligru_persistent_ok(H)
-        if persistent:
+        ctx.gru_persistent = kind == "GRU" and gru_persistent_ok(H)
+        if ctx.gru_persistent:
+            # both hand-offs of a step inside one persistent launch per row-tile group (gatedcell.hip)
+            vg = torch.empty(lib.sparch_gru_vpack_bytes(H, 0, 0) // 4, dtype=torch.float32, device=dev)
+            vc = torch.empty(lib.sparch_gru_vpack_bytes(H, 0, 1) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_gru_vpack(H, ptr(P["z"]["V"]), ptr(P["r"]["V"]), ptr(P["c"]["V"]), 0, ptr(vg), ptr(vc),
+                                       _stream()), "sparch_gru_vpack")
+            nbytes = lib.sparch_gru_chan_bytes(Bp, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            tok = timer.start("gru_fwd")
+            check(lib.sparch_gru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
+                                     ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]),
+                                     ptr(proj["r"]["z_in"]), ptr(proj["r"]["sc"]), ptr(proj["r"]["sh"]), ptr(vg), ptr(vc),
+                                     p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
+                                     ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                  "sparch_gru_fwd")
+            timer.stop(tok)
+        elif persistent:
             # the whole time loop in one persistent launch per row-tile group (gatedcell.hip)
             vp = torch.empty(lib.sparch_ligru_vpack_bytes(H, 0) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_ligru_vpack(H, ptr(P["z"]["V"]), ptr(P["c"]["V"]), 0, ptr(vp), _stream()), "sparch_ligru_vpack")
@@ -1108,7 +1136,21 @@ class GatedLayerFn(torch.autograd.Function):
                 "dz_all": d_all["z"], "dc_all": d_all["c"], "dr_all": d_all.get("r"), "yprev_all": yprev_all,
                 "ry_all": ry_all}
         p_drop, seed = cfg["p_drop"], cfg["seed"]
-        if kind == "LiGRU" and ligru_persistent_ok(H):
+        if kind == "GRU" and ctx.gru_persistent and gru_persistent_ok(H):
+            vg = torch.empty(lib.sparch_gru_vpack_bytes(H, 1, 0) // 4, dtype=torch.float32, device=dev)
+            vc = torch.empty(lib.sparch_gru_vpack_bytes(H, 1, 1) // 4, dtype=torch.float32, device=dev)
+            check(lib.sparch_gru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["r"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vg), ptr(vc),
+                                       _stream()), "sparch_gru_vpack")
+            nbytes = lib.sparch_gru_chan_bytes(Bp, H)
+            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            carry = new(Bp, H)
+            tok = timer.start("gru_bwd")
+            check(lib.sparch_gru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
+                                     ptr(vg), ptr(vc), p_drop, seed, ptr(d_all["z"]), ptr(d_all["r"]), ptr(d_all["c"]),
+                                     ptr(yprev_all), ptr(ry_all), ptr(carry), ptr(chan), nbytes, ptr(status_word(dev)),
+                                     rec_steps_per_launch(T), _stream()), "sparch_gru_bwd")
+            timer.stop(tok)
+        elif kind == "LiGRU" and ligru_persistent_ok(H):
             vpb = torch.empty(lib.sparch_ligru_vpack_bytes(H, 1) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_ligru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vpb), _stream()), "sparch_ligru_vpack")
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)

@@ -1731,3 +1731,86 @@ def test_bf16_saved_states_whole_network(sp, kind, bidir, monkeypatch):
             assert relmax(g_b[k].numpy(), g_a[k].numpy()) <= 2e-2, k
         else:
             assert torch.equal(g_a[k], g_b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bidir,B,T,H", [(False, 40, 23, 128), (True, 36, 17, 256)])
+def test_gru_persistent_kernels_vs_launch_per_step_and_chunked(bidir, B, T, H, monkeypatch):
+    """GRU on the persistent kernels (csrc/gatedcell.hip: 16 hidden units per workgroup, two hand-offs per step —
+    q = r y before the candidate's product, [dz_pre | dr_pre] after dq = dc_pre V in the backward) against the
+    launch-per-step path (same arithmetic, different summation order), with dropout, and chunked launches of the
+    persistent kernels against the whole-sequence launch (bit for bit)."""
+    from sparch_amd.anns import GRULayer
+
+    C = 48
+    torch.manual_seed(41)
+    layer = GRULayer(C, H, B, dropout=0.1, normalization="batchnorm", use_bias=False, bidirectional=bidir).to(DEV).train()
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(B, T, C, generator=g).to(DEV)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g).to(DEV)
+
+    def run(persistent, spl):
+        monkeypatch.setenv("SPARCH_GRU_PERSISTENT", "1" if persistent else "0")
+        monkeypatch.setenv("SPARCH_REC_STEPS_PER_LAUNCH", spl)
+        torch.manual_seed(7)
+        layer._calls = 0  # same dropout seed (initial seed mixed with the layer's call count) in every run
+        layer.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y = layer(xd)
+        (y * gy).sum().backward()
+        _Fn().check_status()
+        return y.detach().cpu(), xd.grad.cpu(), {k: v.grad.cpu().clone() for k, v in layer.named_parameters()}
+
+    y0, dx0, g0 = run(True, "")
+    y1, dx1, g1 = run(False, "")
+    assert float(y0.abs().max()) > 0
+    assert relmax(y0.numpy(), y1.numpy()) <= 1e-5 and relmax(dx0.numpy(), dx1.numpy()) <= 5e-5
+    for k in g0:
+        assert relmax(g0[k].numpy(), g1[k].numpy()) <= 1e-4, k
+    for spl in ("5", "1"):
+        y2, dx2, g2 = run(True, spl)
+        assert torch.equal(y2, y0) and torch.equal(dx2, dx0), spl
+        for k in g0:
+            assert torch.equal(g2[k], g0[k]), (spl, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H,bidir", [(3, 7, 32, False), (33, 11, 96, True), (70, 5, 160, False), (9, 6, 1024, True)])
+def test_gru_persistent_shape_sweep_vs_oracle(B, T, H, bidir, monkeypatch):
+    """Ragged batches, partial k-group coverage per wave, the largest supported size, both directions: the
+    persistent GRU against the CPU oracle (oracle/ann_oracle.py, pinned by tests/golden/ann_GRU*.npz) and against
+    the launch-per-step path."""
+    from oracle import ann_oracle as ao
+    from sparch_amd.anns import GRULayer
+
+    C = 20
+    torch.manual_seed(B + H)
+    layer = GRULayer(C, H, B, dropout=0.0, normalization="layernorm", use_bias=True, bidirectional=bidir).train()
+    p = {"ann.0." + k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(DEV)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, C, generator=g)
+    gy = torch.randn(B, T, H * (2 if bidir else 1), generator=g)
+
+    def run(persistent):
+        monkeypatch.setenv("SPARCH_GRU_PERSISTENT", "1" if persistent else "0")
+        layer.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        y = layer(xd)
+        (y * gy.to(DEV)).sum().backward()
+        _Fn().check_status()
+        return y.detach().cpu(), xd.grad.cpu(), {k: v.grad.cpu().clone() for k, v in layer.named_parameters()}
+
+    y0, dx0, g0 = run(True)
+    y1, dx1, g1 = run(False)
+    assert relmax(y0.numpy(), y1.numpy()) <= 2e-5 and relmax(dx0.numpy(), dx1.numpy()) <= 5e-5
+    for k in g0:
+        assert relmax(g0[k].numpy(), g1[k].numpy()) <= 1e-4, k
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = ao.hidden_layer("GRU", xr, pr, "ann.0", "layernorm", bidir, training=True, running=None)
+    (ref * gy).sum().backward()
+    assert relmax(y0.numpy(), ref.detach().numpy()) <= 2e-5
+    assert relmax(dx0.numpy(), xr.grad.numpy()) <= 2e-4
+    for k, v in g0.items():
+        assert relmax(v.numpy(), pr["ann.0." + k].grad.numpy()) <= 2e-4, k
