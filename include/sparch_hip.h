@@ -423,6 +423,14 @@ int sparch_ligru_bwd(int B, int dirs, int T, int H, const float* g_out, const fl
                      void* chan, size_t chan_bytes, uint32_t* status, int steps_per_launch,
                      void* stream);
 
+/* Host routine (no device work): n uniform fp32 numbers in [0, 1) from an MT19937 state, exactly as torch.rand draws
+ * them from its CPU generator — one 32-bit output y per element, x = (y & 0xFFFFFF) * 2^-24 — i.e. the reference's
+ * initial-state draws (snns.py:286-287, 423-425, 558-559, 700-702, 812) at ~1 ns instead of ~5 ns per number.
+ * key: the 624 state words, *pos: index of the next word (624 = regenerate first); both are advanced in place.  The
+ * caller moves them out of / back into the generator's serialized state (sparch_amd/snns.py, which also verifies the
+ * layout once against torch.rand and otherwise keeps drawing with torch.rand).                              */
+int sparch_mt19937_uniform_f32(uint32_t* key, int* pos, size_t n, float* out);
+
 /* GRU cell (GRULayer._gru_cell, anns.py:581-595) as persistent kernels: the same machine with a second hand-off
  * per step (the reset gate sits inside the candidate's recurrent term):
  *   z = sigmoid(xz + y Vz^T), r = sigmoid(xr + y Vr^T), c = tanh(xc + (r y) V^T), y' = z y + (1 - z) c.

@@ -105,6 +105,7 @@ PROTOTYPES = {
                                  c_size_t, P, c_int, P]),
     "sparch_ligru_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_uint64, P, P, P, P, P,
                                  c_size_t, P, c_int, P]),
+    "sparch_mt19937_uniform_f32": (c_int, [P, P, c_size_t, P]),
     "sparch_gru_vpack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sparch_gru_vpack": (c_int, [c_int, P, P, P, c_int, P, P, P]),
     "sparch_gru_chan_bytes": (c_size_t, [c_int, c_int]),

@@ -16,6 +16,9 @@ instead of materialising `cat(all_spikes)` (snns.py:174).
 """
 import math
 
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 
@@ -57,12 +60,101 @@ def _spike_tag(x):
     return tag[2], tag[3]
 
 
+# ---- initial-state draws.  The reference draws every layer's u0, [w0,] s0 with torch.rand from the global CPU
+# generator at each forward (snns.py:286-287, 423-425, 558-559, 700-702, 812).  The values below are the same
+# numbers from the same generator in the same order; what differs is who computes them: torch's serial loop
+# costs ~5 ns per number (8.5 ms per step at the headline shape, more than the GPU needs for the step), the
+# library's host routine `sparch_mt19937_uniform_f32` ~1 ns.  It works on the generator's serialized MT19937
+# state (CPUGeneratorImplStateLegacy: seed u64, left i32, seeded i32, next u64, 624 state words as u64, ...),
+# which is moved out, advanced, and written back — so anything else drawing from the global generator before or
+# after sees the stream it would have seen.  The layout is verified once against torch.rand on a private
+# generator; if that check ever fails (another torch build), the draws simply stay with torch.rand.
+_MT_WORDS, _MT_OFF_LEFT, _MT_OFF_NEXT, _MT_OFF_KEY, _MT_STATE_BYTES = 624, 8, 16, 24, 24 + 624 * 8
+
+
+def _mt_draw(state_bytes, outs):
+    """Fill the fp32 CPU tensors `outs` (contiguous) in order from the serialized generator state
+    `state_bytes` (uint8 tensor, modified in place).  Returns False if the state is not one this code reads."""
+    import numpy as np
+
+    raw = state_bytes.numpy()
+    if raw.size < _MT_STATE_BYTES:
+        return False
+    left = int(raw[_MT_OFF_LEFT:_MT_OFF_LEFT + 4].view(np.int32)[0])
+    nxt = int(raw[_MT_OFF_NEXT:_MT_OFF_NEXT + 8].view(np.uint64)[0])
+    key64 = raw[_MT_OFF_KEY:_MT_OFF_KEY + _MT_WORDS * 8].view(np.uint64)
+    if not (1 <= left <= _MT_WORDS and nxt <= _MT_WORDS and (left == 1 or left == _MT_WORDS + 1 - nxt)):
+        return False
+    key = key64.astype(np.uint32)
+    pos = ctypes.c_int(_MT_WORDS if left == 1 else nxt)
+    for t in outs:
+        Fn.check(Fn.lib.sparch_mt19937_uniform_f32(key.ctypes.data, ctypes.byref(pos), t.numel(), t.data_ptr()),
+                 "sparch_mt19937_uniform_f32")
+    key64[:] = key
+    p = pos.value
+    raw[_MT_OFF_NEXT:_MT_OFF_NEXT + 8].view(np.uint64)[0] = p
+    raw[_MT_OFF_LEFT:_MT_OFF_LEFT + 4].view(np.int32)[0] = 1 if p == _MT_WORDS else _MT_WORDS + 1 - p
+    return True
+
+
+_fast_rand_ok = None
+
+
+def _fast_rand_available():
+    """One-time check of the serialized-state layout: 300 k numbers across many block boundaries from a private
+    generator, by torch.rand and by the host routine; the generator must also end in the same state."""
+    global _fast_rand_ok
+    if _fast_rand_ok is None:
+        ok = False
+        if os.environ.get("SPARCH_FAST_RAND", "1") != "0":
+            try:
+                g = torch.Generator()
+                g.manual_seed(0x5eed)
+                torch.rand(7, generator=g)  # somewhere inside a block
+                st = g.get_state().clone()
+                want = [torch.rand(300, 1001, generator=g), torch.rand(5, generator=g)]
+                got = [torch.empty(300, 1001), torch.empty(5)]
+                ok = _mt_draw(st, got) and all(torch.equal(a, b) for a, b in zip(want, got)) \
+                    and torch.equal(st, g.get_state())
+            except Exception:  # any surprise in the layout: keep torch.rand
+                ok = False
+        _fast_rand_ok = ok
+    return _fast_rand_ok
+
+
+def _rand_batch(shapes, device):
+    """torch.rand(*shape) for every shape, in order, from the global CPU generator — as ONE pinned staging
+    buffer and one asynchronous copy; returns the device tensors (views of one allocation, 256-byte aligned)."""
+    if _rand_to is not _rand_to_default:  # a caller substituted the per-tensor draw (tests inject fixture states)
+        return [_rand_to(r, c, device) for r, c in shapes]
+    sizes = [int(r) * int(c) for r, c in shapes]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    on_gpu = device.type == "cuda"
+    host = torch.empty(total, dtype=torch.float32, pin_memory=on_gpu)
+    views = [host[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)]
+    done = False
+    if _fast_rand_available():
+        st = torch.get_rng_state()
+        done = _mt_draw(st, views)
+        if done:
+            torch.set_rng_state(st)
+    if not done:
+        for v in views:
+            torch.rand(v.shape[0], v.shape[1], out=v)
+    dev = host.to(device, non_blocking=True) if on_gpu else host.to(device)
+    return [dev[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)]
+
+
 def _rand_to(rows, cols, device):
     """torch.rand from the global CPU generator (the reference's source of initial states), staged
     in pinned memory and copied asynchronously so the host does not stall once per layer."""
-    if device.type == "cuda":
-        return torch.rand(rows, cols, pin_memory=True).to(device, non_blocking=True)
-    return torch.rand(rows, cols).to(device)
+    return _rand_batch([(rows, cols)], device)[0]
+
+
+_rand_to_default = _rand_to
 
 
 def _make_norm(normalization, hidden_size):
@@ -357,12 +449,25 @@ class SNN(nn.Module):
         reference's order (per hidden layer u, [w], s; then the readout's u): a list with one (u0, w0, s0)
         tuple per hidden layer and the readout's u0 tensor last."""
         last = self.num_layers - 1
-        states = []
+        shapes, plan = [], []
         for i, layer in enumerate(self.snn):
             if self.use_readout_layer and i == last:
-                states.append(_rand_to(batch, layer.hidden_size, device))
+                shapes.append((batch, layer.hidden_size))
+                plan.append(None)
             else:
-                states.append(layer._draw_states(batch * (2 if layer.bidirectional else 1), device))
+                rows = batch * (2 if layer.bidirectional else 1)
+                adaptive = layer.kind in ("adLIF", "RadLIF")
+                shapes += [(rows, layer.hidden_size)] * (3 if adaptive else 2)
+                plan.append(adaptive)
+        drawn = iter(_rand_batch(shapes, device))  # one staging buffer, one copy for the whole forward
+        states = []
+        for adaptive in plan:
+            if adaptive is None:
+                states.append(next(drawn))
+            else:
+                u0 = next(drawn)
+                w0 = next(drawn) if adaptive else None
+                states.append((u0, w0, next(drawn)))
         return states
 
     def draw_states_into(self, static_states, batch):

@@ -149,3 +149,47 @@ def test_spiking_dataset_api_and_errors():
     # the import path of the reference resolves to the same classes
     from sparch.dataloaders.spiking_datasets import SpikingDataset as S2
     assert S2 is SpikingDataset
+
+
+def test_initial_state_draws_are_torch_rand_bit_for_bit():
+    """The host routine behind SNN.draw_states (sparch_mt19937_uniform_f32 on the generator's serialized state)
+    must give the numbers torch.rand gives, in the same order, and leave the global generator where torch.rand
+    would have left it (the next draw of anything else is unchanged) — from any position inside a block."""
+    from sparch_amd import snns
+
+    assert snns._fast_rand_available(), "layout check against torch.rand failed: the fast path is off"
+    shapes = [(256, 1024), (256, 1024), (256, 1024), (64, 35), (3, 5), (1, 1)]
+    for warm in (0, 1, 623, 624, 625, 1000):
+        torch.manual_seed(1234 + warm)
+        torch.rand(warm) if warm else None
+        want = [torch.rand(r, c) for r, c in shapes]
+        tail_want = torch.randn(11)  # a different kind of draw afterwards
+        torch.manual_seed(1234 + warm)
+        torch.rand(warm) if warm else None
+        got = snns._rand_batch(shapes, torch.device("cpu"))
+        tail_got = torch.randn(11)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        assert torch.equal(tail_want, tail_got)
+
+
+def test_snn_draw_states_order_and_fallback(monkeypatch):
+    """SNN.draw_states: one batch in the reference's order (per hidden layer u, [w], s, then the readout's u);
+    the torch.rand fallback (SPARCH_FAST_RAND=0 / failed layout check) gives the same tensors."""
+    from sparch_amd import snns
+
+    def draw(fast):
+        monkeypatch.setattr(snns, "_fast_rand_ok", fast)
+        net = snns.SNN((6, None, 20), [32, 32, 5], neuron_type="RadLIF", dropout=0.0, normalization="none",
+                       bidirectional=True)
+        torch.manual_seed(77)
+        st = net.draw_states(6, torch.device("cpu"))
+        return st, torch.rand(3)
+
+    (a, ta), (b, tb) = draw(True), draw(False)
+    torch.manual_seed(77)
+    ref = [torch.rand(12, 32) for _ in range(6)] + [torch.rand(6, 5)]
+    flat = lambda st: [t for x in st for t in (x if isinstance(x, tuple) else (x,))]  # noqa: E731
+    for x, y, z in zip(flat(a), flat(b), ref):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert torch.equal(ta, tb)
