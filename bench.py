@@ -268,6 +268,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
+    host_dt = time.perf_counter() - t0  # host time to ENQUEUE the steps (close to dt = the host is the bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,6 +355,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["avg_ms"] * v["launches"] / args.steps, 4) for k, v in kern.items()},
             "final_loss": final_loss,
+            # host time to enqueue one step (no synchronisation inside): well below ms_per_step = the GPU is the bound
+            "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
         }
         if note:
             line["note"] = note

@@ -254,6 +254,9 @@ size_t sparch_vpack_bytes(int H);
 /* transpose: bit 0 = pack V^T, bit 1 = keep the diagonal (dense cells of the ANN baselines) */
 int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked,
                  void* stream);
+/* The forward fragments, the backward (transposed) fragments and the masked copy in one launch (a training step
+ * needs all three; vmasked may be NULL).                                                                    */
+int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream);
 /* vmasked (H,H) = V with its diagonal zeroed (snns.py:566/712), any H */
 int sparch_vmask(int H, const float* V, float* vmasked, void* stream);
 size_t sparch_rec_chan_bytes(int Bp, int T, int H);
@@ -305,7 +308,7 @@ int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H, int t, con
                              const float* bn_mean, const float* bn_invstd, float* dwx_step, void* stream);
 
 /* Finish per-row partials: out[j][h] = sum_r ws[j][r][h], zeroed where the raw parameter
- * lies outside [lo_j, hi_j] (torch.clamp's gradient gate).  n_params <= 4; raw[j]/lim may
+ * lies outside [lo_j, hi_j] (torch.clamp's gradient gate).  n_params <= 8; raw[j]/lim may
  * be NULL for "no clamp".                                                             */
 int sparch_colsum_clamped(int n_params, int rows, int H, const float* ws,
                           const float* const* raw, const float* lim_lo_hi, float* const* out,

@@ -68,6 +68,7 @@ PROTOTYPES = {
                                 c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_vpack_bytes": (c_size_t, [c_int]),
     "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
+    "sparch_vpack_both": (c_int, [c_int, P, P, P, P, P]),
     "sparch_vmask": (c_int, [c_int, P, P, P]),
     "sparch_rec_chan_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sparch_rec_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,

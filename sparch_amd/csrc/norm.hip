@@ -290,10 +290,10 @@ __global__ void add_halves_kernel(size_t n, const float* __restrict__ x, float* 
 
 // out[j][h] = gate_j(h) * sum_r ws[j][r][h]
 struct ClampArgs {
-    const float* raw[4];
-    float* out[4];
-    float lo[4], hi[4];
-    int gated[4];
+    const float* raw[8];
+    float* out[8];
+    float lo[8], hi[8];
+    int gated[8];
 };
 __global__ __launch_bounds__(256) void colsum_clamped_kernel(int n_params, int rows, int H,
                                                              const float* __restrict__ ws, ClampArgs a) {
@@ -435,7 +435,7 @@ extern "C" int sparch_colsum_clamped(int n_params, int rows, int H, const float*
                                      const float* const* raw, const float* lim_lo_hi, float* const* out,
                                      void* stream) {
     SPARCH_ENTER();
-    if (n_params < 1 || n_params > 4 || rows <= 0 || H <= 0 || !ws || !out) return SPARCH_EINVAL;
+    if (n_params < 1 || n_params > 8 || rows <= 0 || H <= 0 || !ws || !out) return SPARCH_EINVAL;
     ClampArgs a{};
     for (int j = 0; j < n_params; ++j) {
         if (!out[j]) return SPARCH_EINVAL;

@@ -977,6 +977,45 @@ __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const floa
         vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane] = o;
     }
 }
+// forward fragments, backward (transposed) fragments and the masked copy of a spiking layer's V in ONE launch (a
+// training step needs all three; three launches were ~25 us of launch + queue gaps per layer)
+__global__ void vpack_both_kernel(int H, int n_ct, int nkg, const float* __restrict__ V, u32x4* __restrict__ vpack_f,
+                                  u32x4* __restrict__ vpack_b, float* __restrict__ Vm) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_ct * nkg * 2 * 64;
+    if (idx < total) {
+        const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 1);
+        const int kg = (int)((idx >> 7) % nkg), ct = (int)((idx >> 7) / nkg);
+        const int col = ct * 32 + (lane & 31);
+        unsigned short pf[3][8], pb[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
+            const bool in = k < H && col < H && k != col;
+            split3(in ? V[(size_t)k * H + col] : 0.f, pf[0][j], pf[1][j], pf[2][j]);
+            split3(in ? V[(size_t)col * H + k] : 0.f, pb[0][j], pb[1][j], pb[2][j]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            u32x4 of, ob;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                of[q] = (unsigned)pf[p][2 * q] | ((unsigned)pf[p][2 * q + 1] << 16);
+                ob[q] = (unsigned)pb[p][2 * q] | ((unsigned)pb[p][2 * q + 1] << 16);
+            }
+            const size_t o = ((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane;
+            vpack_f[o] = of;
+            vpack_b[o] = ob;
+        }
+    }
+    if (Vm) {
+        const size_t n = (size_t)H * H, stride = (size_t)gridDim.x * blockDim.x;
+        for (size_t e = idx; e < n; e += stride) {
+            const int i = (int)(e / H), j = (int)(e % H);
+            Vm[e] = (i == j) ? 0.f : V[e];
+        }
+    }
+}
 __global__ void vmask_kernel(int H, const float* __restrict__ V, float* __restrict__ Vm) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)H * H) return;
@@ -1186,6 +1225,19 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
         hipLaunchKernelGGL(vmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, H, V, vmasked);
         SPARCH_CHECK_LAUNCH();
     }
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream) {
+    SPARCH_ENTER();
+    const int kgw = pick_kgw(H);
+    if (H <= 0 || kgw == 0 || !V || !vpack_fwd || !vpack_bwd) return SPARCH_EINVAL;
+    if (!aligned16(vpack_fwd) || !aligned16(vpack_bwd)) return SPARCH_EALIGN;
+    const int n_ct = cdiv(H, CT), nkg = 4 * kgw;
+    const size_t total = (size_t)n_ct * nkg * 2 * 64;
+    hipLaunchKernelGGL(vpack_both_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, n_ct,
+                       nkg, V, reinterpret_cast<u32x4*>(vpack_fwd), reinterpret_cast<u32x4*>(vpack_bwd), vmasked);
+    SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
 

@@ -468,10 +468,14 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
                                                    ptr(count), ptr(s_step), _stream()), "sparch_rec_cell_step_fwd")
             timer.stop(tok)
             return s_out, count, (u_save, w_save), s16
+        # forward fragments, backward fragments (kept for cell_backward) and the masked copy: one launch
         vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+        vpack_t = torch.empty_like(vpack)
         vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
-        check(lib.sparch_vpack(H, ptr(V), 0, ptr(vpack), ptr(vmask), _stream()), "sparch_vpack")
-        rec0 = gemm_nn(s0, vmask)  # t = 0 drive: s0 is uniform noise, not binary (snns.py:559/702)
+        check(lib.sparch_vpack_both(H, ptr(V), ptr(vpack), ptr(vpack_t), ptr(vmask), _stream()), "sparch_vpack_both")
+        # t = 0 drive: s0 is uniform noise, not binary (snns.py:559/702): a (B', H, H) dense product, split-K so
+        # that its 16 output tiles become a full grid (38 -> ~15 us at B' = 256, H = 1024)
+        rec0 = _gemm_small(s0, vmask, nn=True)
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         tok = timer.start(f"rec_cell_fwd[{kind}]")
@@ -481,6 +485,7 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
                                       ptr(s16), ptr(u_save), ptr(w_save), int(save16), ptr(count), ptr(chan),
                                       nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
         timer.stop(tok)
+        return s_out, count, (u_save, w_save, vpack_t), s16
     return s_out, count, (u_save, w_save), s16
 
 
@@ -493,7 +498,8 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     dev = g_out.device
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
-    u_save, w_save = saved
+    u_save, w_save = saved[0], saved[1]
+    vpack_fwd_made = saved[2] if len(saved) > 2 else None  # backward fragments of V packed by cell_forward
     save16 = u_save.dtype == torch.bfloat16
     dWx = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
     n_base = 6 if recurrent else 4
@@ -528,8 +534,11 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                                                    _stream()), "sparch_rec_cell_step_bwd")
             timer.stop(tok)
         else:
-            vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
+            if vpack_fwd_made is not None:
+                vpack_t = vpack_fwd_made
+            else:
+                vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
+                check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
             L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
@@ -553,10 +562,16 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
         grads["V"] = dV
     names = ["alpha"] + (["beta", "a", "b"] if adaptive else [])
     lims = [ALPHA_LIM] + ([BETA_LIM, A_LIM, B_LIM] if adaptive else [])
-    outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names], lims)
+    if bn is None:
+        outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names], lims)
+    else:
+        # one launch for the parameter planes and the two BatchNorm planes behind them (no clamp gate there; the
+        # planes in between, if any, are summed too and dropped)
+        n_all = n_base + 2
+        outs = _finish_param_grads(ws, Bp, H, [p[n] for n in names] + [None] * (n_all - len(names)),
+                                   lims + [(0.0, 0.0)] * (n_all - len(names)))
+        grads["bn_sums"] = (outs[n_base], outs[n_base + 1])
     grads.update(dict(zip(names, outs)))
-    if bn is not None:  # column sums of the two BatchNorm planes (no clamp gate)
-        grads["bn_sums"] = tuple(_finish_param_grads(ws[n_base:], Bp, H, [None, None], [(0.0, 0.0)] * 2))
     return dWx, grads
 
 
@@ -697,8 +712,12 @@ class ReadoutLayerFn(torch.autograd.Function):
                                      ptr(ctx.nsaved[0]) if fuse else None, ptr(ctx.nsaved[1]) if fuse else None,
                                      ptr(u_save), ptr(alpha), ptr(u0), ptr(dWx), ptr(ws), _stream()),
               "sparch_readout_bwd")
-        (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
-        sums = tuple(_finish_param_grads(ws[1:], B, C, [None, None], [(0.0, 0.0)] * 2)) if fuse else None
+        if fuse:  # dalpha and BatchNorm's two column sums: one launch
+            dalpha, s1, s2 = _finish_param_grads(ws, B, C, [alpha, None, None], [ALPHA_LIM, (0.0, 0.0), (0.0, 0.0)])
+            sums = (s1, s2)
+        else:
+            (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
+            sums = None
         dy = dWx.view(M, C)
         dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"], sums=sums)
         in_scale = cfg.get("in_spike_scale")
