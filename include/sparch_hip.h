@@ -259,6 +259,12 @@ int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmas
 int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream);
 /* vmasked (H,H) = V with its diagonal zeroed (snns.py:566/712), any H */
 int sparch_vmask(int H, const float* V, float* vmasked, void* stream);
+/* XCD-local hand-off stores of the spiking recurrent kernels (whole-sequence launches): the workgroups of a row
+ * tile establish at run time (HW_REG_XCC_ID exchanged through agent-scope accesses) that they share an XCD and
+ * then hand their tiles over with plain stores, which stay in that XCD's L2; anything else keeps the
+ * write-through agent-scope stores.  Same results bit for bit; on by default (SPARCH_XCD_LOCAL=0 turns it off).
+ * sparch_set_xcd_local(0 / 1) overrides, -1 returns to the environment's setting; returns the previous state.  */
+int sparch_set_xcd_local(int on);
 size_t sparch_rec_chan_bytes(int Bp, int T, int H);
 int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,
                         const float* scale, const float* shift, const float* alpha,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P,
                                 c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_vpack_bytes": (c_size_t, [c_int]),
+    "sparch_set_xcd_local": (c_int, [c_int]),
     "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
     "sparch_vpack_both": (c_int, [c_int, P, P, P, P, P]),
     "sparch_vmask": (c_int, [c_int, P, P, P]),

@@ -206,6 +206,45 @@ __device__ __forceinline__ void split_tile(const u32x4 (&g)[2][2], u32x4 (&P)[2]
             }
 }
 
+// ---- XCD-local hand-off stores (speed option, VERIFIED at run time).
+// Agent-scope (sc1) stores are write-through and drop the line from the XCD's L2: a consumer on the same XCD
+// then fetches it at the cross-XCD rate and latency.  A plain store keeps the line in that L2, where an sc1
+// load of any CU of the XCD finds it (sc1 loads bypass L1 only) — but it is invisible to the other XCDs.
+// Placement is not part of HIP's contract, so nothing may ASSUME that a row tile's workgroups share an XCD:
+// they establish it.  Every workgroup publishes the XCC id of the XCD it runs on (HW_REG_XCC_ID) with an
+// agent-scope store into a table the host cleared, reads the entries of all workgroups of its row tile with
+// agent-scope loads (bounded spin), and only if all are there and equal do these workgroups — all of which
+// see the same entries — use plain stores among themselves.  Anything else (different XCDs, a workgroup
+// that never arrives, chunked launches, an absent table) keeps the sc1 stores.  A wave that finds itself
+// on another XCD later (queue preemption with save / restore) raises the launch's abort flag: the step is
+// discarded and the host goes to per-step launches, exactly as after a timeout.
+constexpr int GETREG_XCC_ID = (3 << 11) | 20;  // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ __forceinline__ unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xFu; }
+
+// tab: this row tile's n_ct (<= 64) words, all `empty` before the launch.  Called by every thread of the
+// workgroup BEFORE a __syncthreads() the caller already has; the result is read from *lds_flag after it.
+__device__ __forceinline__ void xcd_agree(gu32* tab, unsigned empty, int n_ct, int ct, unsigned my_xcc, int tid,
+                                          int* lds_flag) {
+    if (tid >= 64) return;
+    bool ok = tab != nullptr && n_ct <= 64;
+    if (ok) {
+        if (tid == 0) __hip_atomic_store(tab + ct, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < n_ct) {
+            const u64 t_start = __builtin_amdgcn_s_memrealtime();
+            unsigned v = empty;
+            for (unsigned spins = 0;; ++spins) {
+                v = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v != empty) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS / 100) break;  // 20 ms
+            }
+            ok = v == my_xcc + 1u;
+        }
+    }
+    const bool all = __all(ok);
+    if (tid == 0) *lds_flag = all ? 1 : 0;
+}
+
 // Host side: can `grid` workgroups of this kernel be resident at once?  (The persistent launches wait for each
 // other inside the kernel.)  Occupancy as the runtime computes it for this kernel's registers / LDS, times the CU
 // count; cached per kernel.  The in-kernel spins are bounded anyway — this keeps a foreseeable miss (fewer CUs

@@ -84,6 +84,7 @@ struct RecArgs {
     int save16;  // u_save / w_save hold bf16 (common.h save_u16); whole-sequence launches only
     // hand-off
     u64* chan; char* ring; unsigned* status;
+    unsigned* xcd_tab;  // [n_rt_total][n_ct] agreement table of the XCD-local stores (whole-sequence launches), or null
 };
 
 // Diagnostic build only (-DSPARCH_REC_PROF, never shipped): per-workgroup sums of s_memtime
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
     __shared__ int abort_flag[2];
+    __shared__ int xcd_local_flag;
     __shared__ unsigned cnt_lds[2][CT];
 
     const int tid = threadIdx.x;
@@ -175,7 +177,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     }
     if (tid < 2) abort_flag[tid] = 0;
     if (tid < 2 * CT) cnt_lds[tid / CT][tid % CT] = 0;
+    const unsigned my_xcc = xcc_id();
+    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, 0u, a.n_ct, ct, my_xcc, tid, &xcd_local_flag);
     __syncthreads();
+    const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
     const bool has_norm = a.scale != nullptr;
     const bool drop = a.p_drop > 0.0f;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             }
             PROF_STAMP(1);  // expand + MFMA + LDS write
         }
+        if (xcd_local && xcc_id() != my_xcc) raise_timeout(a.status, &abort_flag[t & 1]);  // moved to another XCD
         lds_barrier();
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
@@ -328,7 +334,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             }
         } else if (pw && cq == 0 && t + 1 < T) {
             gu64* slot = (gu64*)a.chan + (((size_t)t * a.n_rt_total + rt) * a.n_ct + ct) * 32 + r;
-            __hip_atomic_store(slot, ((u64)(unsigned)(t + 1) << 32) | (u64)word, __ATOMIC_RELAXED, REC_ST_SCOPE);
+            const u64 granule = ((u64)(unsigned)(t + 1) << 32) | (u64)word;
+            if (xcd_local) __hip_atomic_store(slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(slot, granule, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
         PROF_STAMP(3);  // pointwise + publish
         if (valid) {
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #define PACC(j, i) pacc[j][i]
 #endif
     __shared__ int abort_flag[2];
+    __shared__ int xcd_local_flag;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -465,7 +474,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         u_t[0] = v.x; u_t[1] = v.y; u_t[2] = v.z; u_t[3] = v.w;
     }
     if (tid < 2) abort_flag[tid] = 0;
+    const unsigned my_xcc = xcc_id();
+    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, SENTINEL, a.n_ct, ct, my_xcc, tid, &xcd_local_flag);
     __syncthreads();
+    const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
     // hand-off ring: ring[slot][rt][ct] = one 4 KiB fp32 tile in fragment order; one buffer resource
     const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * TILE_BYTES);
@@ -577,6 +589,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
             PROF_STAMP(1);  // per k-group: wait, split, MFMA; LDS write
         }
+        if (xcd_local && xcc_id() != my_xcc) *(volatile int*)&abort_flag[par] = 1;  // moved to another XCD
         lds_barrier();
         vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
@@ -638,14 +651,16 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 u32x4 rawv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
-                __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, (unsigned)(t % RING) * slot_bytes + tile_off, 0,
-                                                       REC_ST_AUX);
+                const unsigned so = (unsigned)(t % RING) * slot_bytes + tile_off;
+                if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, so, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, so, 0, REC_ST_AUX);
             }
 #ifndef REC_NO_RESET
             if (t + 2 < T) {
                 const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
-                __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (unsigned)((t + 2) % RING) * slot_bytes + tile_off,
-                                                       0, REC_ST_AUX);
+                const unsigned so = (unsigned)((t + 2) % RING) * slot_bytes + tile_off;
+                if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, so, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, so, 0, REC_ST_AUX);
             }
 #endif
         }
@@ -1036,6 +1051,13 @@ size_t fwd_chan_bytes(int Bp, int T, int H) {
 size_t bwd_ring_bytes(int Bp, int H) {
     return (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * TILE_BYTES;
 }
+// agreement table of the XCD-local stores: one word per workgroup, behind the granules / the ring
+size_t xcd_tab_bytes(int Bp, int H) { return (size_t)cdiv(Bp, RT) * cdiv(H, CT) * sizeof(unsigned); }
+int g_xcd_local = -1;  // -1: SPARCH_XCD_LOCAL (default on); 0 / 1: set by sparch_set_xcd_local
+bool xcd_local_enabled() {
+    static const bool env_on = [] { const char* e = getenv("SPARCH_XCD_LOCAL"); return !e || atoi(e) != 0; }();
+    return g_xcd_local < 0 ? env_on : g_xcd_local != 0;
+}
 
 template <bool BWD, bool ADAPT>
 int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
@@ -1079,12 +1101,19 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     a.nkg = 4 * kgw;
     a.n_rt_total = cdiv(a.Bp, RT);
     if (!a.chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
+    // (the agreement table of the XCD-local stores sits behind the granules / the ring and is cleared with them:
+    // "empty" is 0 in the forward's zeroed buffer, the sentinel word in the backward's)
+    const size_t tabb = xcd_tab_bytes(a.Bp, a.H);
     if (!BWD) {
-        if (hipMemsetAsync(a.chan, 0, fwd_chan_bytes(a.Bp, a.T, a.H), st) != hipSuccess) return SPARCH_ELAUNCH;
+        const size_t fb = fwd_chan_bytes(a.Bp, a.T, a.H);
+        if (hipMemsetAsync(a.chan, 0, fb + tabb, st) != hipSuccess) return SPARCH_ELAUNCH;
+        a.xcd_tab = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.chan) + fb);
     } else {  // every ring piece reads "not written yet" until its producer's store lands
-        if (hipMemsetD32Async((hipDeviceptr_t)a.chan, (int)SENTINEL, bwd_ring_bytes(a.Bp, a.H) / 4, st) != hipSuccess)
+        const size_t rb = bwd_ring_bytes(a.Bp, a.H);
+        if (hipMemsetD32Async((hipDeviceptr_t)a.chan, (int)SENTINEL, (rb + tabb) / 4, st) != hipSuccess)
             return SPARCH_ELAUNCH;
         a.ring = reinterpret_cast<char*>(a.chan);
+        a.xcd_tab = reinterpret_cast<unsigned*>(a.ring + rb);
     }
 
     int L = steps_per_launch;
@@ -1107,6 +1136,7 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
             L = 1; rt_per_launch = a.n_rt_total;
         }
     }
+    if (L < a.T || !xcd_local_enabled()) a.xcd_tab = nullptr;  // whole-sequence launches only (one agreement per launch)
     for (int rt0 = 0; rt0 < a.n_rt_total; rt0 += rt_per_launch) {
         a.rt_base = rt0;
         a.n_rt_launch = min(rt_per_launch, a.n_rt_total - rt0);
@@ -1241,6 +1271,12 @@ extern "C" int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float*
     return SPARCH_OK;
 }
 
+extern "C" int sparch_set_xcd_local(int on) {
+    const int was = xcd_local_enabled() ? 1 : 0;
+    g_xcd_local = on < 0 ? -1 : (on != 0);
+    return was;
+}
+
 extern "C" int sparch_vmask(int H, const float* V, float* vmasked, void* stream) {
     SPARCH_ENTER();
     if (H <= 0 || !V || !vmasked) return SPARCH_EINVAL;
@@ -1254,7 +1290,7 @@ extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
     // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: fp32 tile ring
     const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_ring_bytes(Bp, H);
-    return f > b ? f : b;
+    return (f > b ? f : b) + xcd_tab_bytes(Bp, H);
 }
 
 extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,

@@ -42,7 +42,8 @@ def test_host_only_entry_points():
     assert lib.sparch_vpack_bytes(1024) == 1024 * 1024 * 6   # three bf16 planes per fp32 element
     assert lib.sparch_vpack_bytes(100) == 4 * 4 * 1024 * 6  # 4 column tiles x (4 waves x 1 k-group of 32)
     assert lib.sparch_vpack_bytes(2048) == 0                 # V slice would not fit the register file: step path
-    assert lib.sparch_rec_chan_bytes(256, 250, 1024) == 250 * 8 * 32 * 32 * 8
+    # forward granules (T x row tiles x column tiles x 32 rows x 8 B) + one agreement word per workgroup
+    assert lib.sparch_rec_chan_bytes(256, 250, 1024) == 250 * 8 * 32 * 32 * 8 + 8 * 32 * 4
     assert lib.sparch_gemm_tn_workspace_bytes(1024, 1024, 64000) == 16 * 1024 * 1024 * 4
     assert lib.sparch_bn_bwd_workspace_bytes(64000, 1024) == 2 * 250 * 1024 * 4
 

@@ -1814,3 +1814,44 @@ def test_gru_persistent_shape_sweep_vs_oracle(B, T, H, bidir, monkeypatch):
     assert relmax(dx0.numpy(), xr.grad.numpy()) <= 2e-4
     for k, v in g0.items():
         assert relmax(v.numpy(), pr["ann.0." + k].grad.numpy()) <= 2e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+def test_xcd_local_handoff_stores_give_identical_results(kind):
+    """The recurrent kernels' XCD-local hand-off (plain stores among the workgroups of a row tile once they have
+    established, through agent-scope accesses, that they share an XCD) against the agent-scope write-through
+    stores: same spikes, same gradients, bit for bit — whole-sequence launches with several row-tile groups and
+    real-valued V, so that any stale or missed tile would change the result."""
+    from sparch_amd._capi import lib
+
+    Fn = _Fn()
+    Bp, T, H = 300, 40, 1024  # 10 row tiles x 32 column tiles: two co-resident launches on 256 CUs
+    g = torch.Generator().manual_seed(17)
+    Wx = (torch.randn(Bp, T, H, generator=g) * 2.0 + 0.6).to(DEV)
+    V = torch.nn.init.orthogonal_(torch.empty(H, H), generator=g).to(DEV)
+    adaptive = kind == "RadLIF"
+    p = dict(alpha=torch.rand(H, generator=g) * 0.14 + 0.82, beta=torch.rand(H, generator=g) * 0.024 + 0.967,
+             a=torch.rand(H, generator=g) * 2 - 1, b=torch.rand(H, generator=g) * 2)
+    p = {k: v.to(DEV) for k, v in p.items()}
+    u0, w0, s0 = (torch.rand(Bp, H, generator=g).to(DEV) for _ in range(3))
+    gs = torch.randn(Bp, T, H, generator=g).to(DEV)
+
+    def run(on):
+        lib.sparch_set_xcd_local(on)
+        try:
+            Wr = Wx.clone().requires_grad_(True)
+            Vr = V.clone().requires_grad_(True)
+            s = Fn.SpikingCellFn.apply(kind, 1.0, Wr, p["alpha"], p["beta"] if adaptive else None,
+                                       p["a"] if adaptive else None, p["b"] if adaptive else None, Vr, u0,
+                                       w0 if adaptive else None, s0, None)
+            (s * gs).sum().backward()
+            Fn.check_status()
+            return s.detach().clone(), Wr.grad.clone(), Vr.grad.clone()
+        finally:
+            lib.sparch_set_xcd_local(-1)  # back to the environment's setting
+
+    s1, dw1, dv1 = run(1)
+    s0_, dw0, dv0 = run(0)
+    assert float(s1.mean()) > 0.005
+    assert torch.equal(s1, s0_) and torch.equal(dw1, dw0) and torch.equal(dv1, dv0)
