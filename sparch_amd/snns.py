@@ -122,11 +122,13 @@ def _fast_rand_available():
     return _fast_rand_ok
 
 
-def _rand_batch(shapes, device):
+def _rand_batch(shapes, device, out=None):
     """torch.rand(*shape) for every shape, in order, from the global CPU generator — as ONE pinned staging
-    buffer and one asynchronous copy; returns the device tensors (views of one allocation, 256-byte aligned)."""
+    buffer and one asynchronous copy; returns the device tensors (views of one allocation, 256-byte aligned).
+    out: the flat device buffer of an earlier call with the same shapes (`.flat` of its first tensor's list):
+    refilled in place — the static inputs of a captured step."""
     if _rand_to is not _rand_to_default:  # a caller substituted the per-tensor draw (tests inject fixture states)
-        return [_rand_to(r, c, device) for r, c in shapes]
+        return _StateList([_rand_to(r, c, device) for r, c in shapes], None)
     sizes = [int(r) * int(c) for r, c in shapes]
     offs, total = [], 0
     for n in sizes:
@@ -144,8 +146,21 @@ def _rand_batch(shapes, device):
     if not done:
         for v in views:
             torch.rand(v.shape[0], v.shape[1], out=v)
-    dev = host.to(device, non_blocking=True) if on_gpu else host.to(device)
-    return [dev[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)]
+    if out is not None:
+        assert out.numel() == total and out.device == device
+        out.copy_(host, non_blocking=on_gpu)
+        dev = out
+    else:
+        dev = host.to(device, non_blocking=True) if on_gpu else host.to(device)
+    return _StateList([dev[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)], dev)
+
+
+class _StateList(list):
+    """The tensors of one _rand_batch call; `.flat` is the single device allocation they are views of."""
+
+    def __init__(self, tensors, flat):
+        super().__init__(tensors)
+        self.flat = flat
 
 
 def _rand_to(rows, cols, device):
@@ -444,10 +459,11 @@ class SNN(nn.Module):
                 dropout=self.dropout, normalization=self.normalization, use_bias=self.use_bias))
         return layers
 
-    def draw_states(self, batch, device):
+    def draw_states(self, batch, device, out=None):
         """Every layer's initial states for one forward, drawn from torch's global CPU generator in the
         reference's order (per hidden layer u, [w], s; then the readout's u): a list with one (u0, w0, s0)
-        tuple per hidden layer and the readout's u0 tensor last."""
+        tuple per hidden layer and the readout's u0 tensor last.  out: the flat buffer of an earlier call
+        (`self._state_flat`) to refill in place."""
         last = self.num_layers - 1
         shapes, plan = [], []
         for i, layer in enumerate(self.snn):
@@ -459,7 +475,9 @@ class SNN(nn.Module):
                 adaptive = layer.kind in ("adLIF", "RadLIF")
                 shapes += [(rows, layer.hidden_size)] * (3 if adaptive else 2)
                 plan.append(adaptive)
-        drawn = iter(_rand_batch(shapes, device))  # one staging buffer, one copy for the whole forward
+        batch_list = _rand_batch(shapes, device, out=out)  # one staging buffer, one copy for the whole forward
+        self._state_flat = batch_list.flat
+        drawn = iter(batch_list)
         states = []
         for adaptive in plan:
             if adaptive is None:
@@ -468,11 +486,18 @@ class SNN(nn.Module):
                 u0 = next(drawn)
                 w0 = next(drawn) if adaptive else None
                 states.append((u0, w0, next(drawn)))
+        states = _StateList(states, batch_list.flat)
         return states
 
     def draw_states_into(self, static_states, batch):
-        """The same draws (same generator, same order), copied straight from pinned host memory into existing
-        device tensors — the static inputs of a captured step (sparch_amd.graph)."""
+        """The same draws (same generator, same order) written into the EXISTING device tensors `static_states`
+        (an earlier draw_states result) — the static inputs of a captured step (sparch_amd.graph): one staging
+        buffer and one stream-ordered copy into their common allocation."""
+        flat = getattr(static_states, "flat", None)
+        if flat is not None:
+            self.draw_states(batch, flat.device, out=flat)
+            return
+
         def fill(dst):
             dst.copy_(torch.rand(dst.shape[0], dst.shape[1], pin_memory=True), non_blocking=True)
 
