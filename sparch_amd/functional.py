@@ -607,6 +607,8 @@ class SpikingLayerFn(torch.autograd.Function):
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
         p = {k_: v for k_, v in p.items() if v is not None}
+        if cfg.get("states_ready") is not None:  # initial states uploaded on a side stream (snns._rand_batch)
+            cfg["states_ready"]()
         s_out, count, saved, s16 = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B,
                                                 dirs=dirs, theta=theta, p_drop=p_drop, seed=seed)
         inv_keep = 1.0 / (1.0 - p_drop)

@@ -146,27 +146,60 @@ def _rand_batch(shapes, device, out=None):
     if not done:
         for v in views:
             torch.rand(v.shape[0], v.shape[1], out=v)
+    ready = None
     if out is not None:
         assert out.numel() == total and out.device == device
         out.copy_(host, non_blocking=on_gpu)
         dev = out
+    elif on_gpu:
+        # The upload (7 MB at the headline shape: ~150 us on the DMA engine) goes on a side stream, so that it
+        # runs under whatever the compute stream does before it first needs a state (the first layer's
+        # projection): in stream order it sat between two steps with the GPU idle.  `.ready` is the event
+        # the consumer waits for (SNN.forward hands it to the first layer's cell call).
+        main = torch.cuda.current_stream(device)
+        side = _upload_stream(device)
+        with torch.cuda.stream(side):
+            dev = host.to(device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        dev.record_stream(main)  # allocated on the side stream's pool, consumed on the compute stream
     else:
-        dev = host.to(device, non_blocking=True) if on_gpu else host.to(device)
-    return _StateList([dev[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)], dev)
+        dev = host.to(device)
+    return _StateList([dev[o:o + n].view(r, c) for o, n, (r, c) in zip(offs, sizes, shapes)], dev, ready)
+
+
+_upload_streams = {}
+
+
+def _upload_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _upload_streams:
+        _upload_streams[key] = torch.cuda.Stream(device=device)
+    return _upload_streams[key]
 
 
 class _StateList(list):
-    """The tensors of one _rand_batch call; `.flat` is the single device allocation they are views of."""
+    """The tensors of one _rand_batch call; `.flat` is the single device allocation they are views of, `.ready`
+    the event of their upload (None: already ordered on the compute stream)."""
 
-    def __init__(self, tensors, flat):
+    def __init__(self, tensors, flat, ready=None):
         super().__init__(tensors)
         self.flat = flat
+        self.ready = ready
+
+    def wait_ready(self):
+        """Make the current stream wait for the upload (no-op when it was stream-ordered)."""
+        if self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
+            self.ready = None
 
 
 def _rand_to(rows, cols, device):
     """torch.rand from the global CPU generator (the reference's source of initial states), staged
     in pinned memory and copied asynchronously so the host does not stall once per layer."""
-    return _rand_batch([(rows, cols)], device)[0]
+    batch = _rand_batch([(rows, cols)], device)
+    batch.wait_ready()
+    return batch[0]
 
 
 _rand_to_default = _rand_to
@@ -274,10 +307,12 @@ class _SpikingLayer(nn.Module):
         return p
 
     # ------------------------------------------------------------------ forward
-    def forward_with_rate(self, x, states=None):
+    def forward_with_rate(self, x, states=None, states_ready=None):
         """Returns (spikes (B,T,H*(1+bidir)), firing_rate (H*(1+bidir),)).  Equivalent to the
         reference forward (e.g. snns.py:663-694) followed by `.mean(dim=(0,1))` (174).
-        states: (u0, w0, s0) drawn ahead of time by SNN.forward (same generator, same order)."""
+        states: (u0, w0, s0) drawn ahead of time by SNN.forward (same generator, same order);
+        states_ready: callable that makes the current stream wait for their upload, called after the
+        projection GEMM has been enqueued (the upload runs under it)."""
         Fn._require_device(x, "input")
         dirs = 2 if self.bidirectional else 1
         rows = x.shape[0] * dirs
@@ -300,6 +335,7 @@ class _SpikingLayer(nn.Module):
             # set when x came straight out of one of our spiking layers: entries are 0 or this constant
             "in_spike_scale": in_scale,
             "in_spike16": in_s16,  # the same spikes as a bf16 plane
+            "states_ready": states_ready,
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1
@@ -486,7 +522,7 @@ class SNN(nn.Module):
                 u0 = next(drawn)
                 w0 = next(drawn) if adaptive else None
                 states.append((u0, w0, next(drawn)))
-        states = _StateList(states, batch_list.flat)
+        states = _StateList(states, batch_list.flat, batch_list.ready)
         return states
 
     def draw_states_into(self, static_states, batch):
@@ -530,11 +566,16 @@ class SNN(nn.Module):
         if states is None:
             states = self.draw_states(x.shape[0], x.device)
         rates = []
+        wait = getattr(states, "wait_ready", None)  # the states' upload runs under the first projection GEMM
         for i, layer in enumerate(self.snn):
             if self.use_readout_layer and i == last:
+                if wait is not None:
+                    wait()
                 x = layer(x, u0=states[i])
             else:
-                x, r = layer.forward_with_rate(x, states=states[i])
+                x, r = layer.forward_with_rate(x, states=states[i], states_ready=wait if i == 0 else None)
+                if wait is not None:
+                    wait()  # (no-op once the first layer's call has waited)
                 rates.append(r)
         firing_rates = torch.cat(rates) if len(rates) > 1 else rates[0]
         return x, firing_rates

@@ -727,8 +727,8 @@ def _run_dyadic(sp, name, monkeypatch):
     monkeypatch.setattr(snn_mod, "_rand_to", next_state)
     rec = {}
     for k, lay in enumerate(list(net.snn)[:-1]):
-        def wrapped(inp, states=None, orig=lay.forward_with_rate, k=k):
-            s, r = orig(inp, states=states)
+        def wrapped(inp, states=None, orig=lay.forward_with_rate, k=k, **kw):
+            s, r = orig(inp, states=states, **kw)
             rec[k] = s.detach()
             return s, r
         lay.forward_with_rate = wrapped
