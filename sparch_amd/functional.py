@@ -612,7 +612,7 @@ class SpikingLayerFn(torch.autograd.Function):
         s_out, count, saved, s16 = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B,
                                                 dirs=dirs, theta=theta, p_drop=p_drop, seed=seed)
         inv_keep = 1.0 / (1.0 - p_drop)
-        rate = count.to(torch.float32) * (inv_keep / float(B * T))  # snns.py:174 on post-dropout spikes
+        rate = count * (inv_keep / float(B * T))  # snns.py:174 on post-dropout spikes (int32 * float -> fp32, one kernel)
         ctx.cfg = cfg
         ctx.shape = (B, T, K, H)
         ctx.nsaved = nsaved

@@ -14,9 +14,8 @@ instead of materialising `cat(all_spikes)` (snns.py:174).
 
 `sparch.models.snns` (repo root) re-exports this module under the reference's import path.
 """
-import math
-
 import ctypes
+import math
 import os
 
 import torch
