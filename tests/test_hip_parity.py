@@ -174,6 +174,8 @@ def test_gemm_presplit_weight_planes_are_bit_identical(M, N, K):
     the fp32 weights on the fly: the planes sum back to W exactly and both products match bit for bit — on
     shapes the pipelined plane kernel takes and on shapes where the _wp entries fall back."""
     Fn = _Fn()
+    if not Fn.USE_PRESPLIT:
+        pytest.skip("SPARCH_PRESPLIT=0")
     g = torch.Generator().manual_seed(M + 7 * N + K)
     W = (torch.randn(N, K, generator=g) * torch.exp(4 * torch.randn(N, K, generator=g))).to(DEV)
     planes = Fn.split_planes(W)
