@@ -1857,3 +1857,28 @@ def test_xcd_local_handoff_stores_give_identical_results(kind):
     s0_, dw0, dv0 = run(0)
     assert float(s1.mean()) > 0.005
     assert torch.equal(s1, s0_) and torch.equal(dw1, dw0) and torch.equal(dv1, dv0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C", [(3, 1, 5), (5, 257, 7), (2, 1000, 35), (4, 300, 256), (7, 513, 1), (9, 64, 64)])
+def test_readout_cell_shape_sweep_vs_oracle(B, T, C):
+    """The staged readout kernels across their chunking rules: sequences longer than one 256-step chunk, chunk
+    lengths bounded by LDS at many classes, a single step, a single class (odd / even row strides, ragged last
+    staging sweep), against the oracle; the value is bit-exact in u (serial recurrence, same order) so the output
+    may differ only by the softmax's rounding."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(B * 1000 + T + C)
+    Wx = torch.randn(B, T, C, generator=g) * 1.5
+    alpha = torch.rand(C, generator=g) * 0.3 + 0.72
+    u0 = torch.rand(B, C, generator=g)
+    g_out = torch.randn(B, C, generator=g)
+    Wr, ar = Wx.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref = orc.readout_cell(Wr, ar, u0)
+    (ref * g_out).sum().backward()
+    Wd, ad = Wx.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+    out = Fn.ReadoutCellFn.apply(Wd, ad, u0.to(DEV))
+    (out * g_out.to(DEV)).sum().backward()
+    Fn.check_status()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=3e-5, atol=3e-5 * max(1, T / 100))
+    assert relmax(Wd.grad.cpu().numpy(), Wr.grad.numpy()) <= 2e-4
+    assert relmax(ad.grad.cpu().numpy(), ar.grad.numpy()) <= 5e-4
