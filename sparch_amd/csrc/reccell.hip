@@ -26,23 +26,27 @@
 //                  with one agent-scope (sc1, write-through) store each and polled with sc1
 //                  loads: the data is the flag, no fence (MI355X guide, G16 form R2).  One slot
 //                  per (step, row): never reused inside a call;
-//       backward — the fp32 32x32 tile of dWx_t, stored in MFMA-FRAGMENT ORDER (16-byte piece
-//                  (ks*2+q)*64 + h*32 + row) into a depth-4 ring with 16-byte sc1 (write-through)
-//                  stores, and NOTHING ELSE: no drain, no tag.  The data is the flag here too: every
-//                  ring slot holds a SENTINEL bit pattern (a signalling NaN, which no fp32 arithmetic
-//                  result can be: hardware quiets NaNs) until its 16-byte piece lands, and consumers
-//                  simply load the tile (16-byte sc1 loads, every wave-load one contiguous 1 KiB) and
-//                  re-load the pieces that still read as the sentinel (first and last word checked;
-//                  16-byte sc1 stores are observed untorn on gfx950).  A producer puts the sentinel
-//                  back into its slot of step t+2 while it works on step t: by then it has seen every
-//                  peer's step t+1 tile, which they produced after consuming every step t+2 tile, and
-//                  its next vmcnt(0) (the tile loads of step t-1) retires that store before it
-//                  publishes step t-1 — the store a consumer must see before it can ask for step t-2,
-//                  the slot's next content.  Against the first version (tile stores, drain, barrier,
-//                  tag store; consumers poll the tag, barrier, then load): one store->load visibility
-//                  hop instead of two per step and two workgroup barriers fewer.  Consumers split the
-//                  fp32 values into three exact bf16 planes in registers (truncation split: v_perm for
-//                  the high halves, AND + SUB for the residuals);
+//       backward — the 32x32 tile of dWx_t as three PRE-SPLIT bf16 planes (x = t1 + t2 + t3 exactly: truncation
+//                  split by v_perm / AND / SUB in the producer), stored in MFMA-FRAGMENT ORDER (16-byte piece
+//                  ((ks*3 + p)*64 + h*32 + row) = plane p, k = 16 ks + 8 h + 0..7) into a depth-4 ring, and
+//                  NOTHING ELSE: no drain, no tag.  The data is the flag here too: every ring slot holds a
+//                  SENTINEL bit pattern (a signalling NaN, which no fp32 arithmetic result can be — and no
+//                  plane word either: its upper half would be a signalling-NaN bf16) until its piece lands,
+//                  and consumers simply load the tile (16-byte sc1 loads, every wave-load one contiguous
+//                  1 KiB = the MFMA A fragments of one k16-step and plane) and re-load the pieces that still
+//                  read as the sentinel (first and last word checked: a producer thread owns 4 consecutive k,
+//                  i.e. half a piece, written with one 8-byte store per plane; 8- and 16-byte stores are
+//                  observed untorn on gfx950).  A producer puts the sentinel back into its slot of step t+2
+//                  while it works on step t: by then it has seen every peer's step t+1 tile, which they
+//                  produced after consuming every step t+2 tile, and its next vmcnt(0) (the tile loads of
+//                  step t-1) retires that store before it publishes step t-1 — the store a consumer must see
+//                  before it can ask for step t-2, the slot's next content.  Against the first version (tile
+//                  stores, drain, barrier, tag store; consumers poll the tag, barrier, then load): one
+//                  store->load visibility hop instead of two per step and two workgroup barriers fewer.
+//                  Until the XCD-local stores the wire carried fp32 (4 KB per tile) and each of the 32
+//                  consumers split the same values (2.8 k VALU cycles per SIMD and step); with the tiles
+//                  served by the XCD's own L2 the 6 KB plane tiles are the faster trade (1.34 -> 1.27 ms per
+//                  launch; timing ablations: no split at 4 KB 1.16, no split at 6 KB 1.27);
 //   * block -> tile mapping keeps a batch tile's workgroups at equal blockIdx % n_row_tiles,
 //     i.e. on one XCD under round-robin dispatch.  That is a speed choice only: every
 //     hand-off is agent-scope and placement-independent.  Every spin is bounded by a
@@ -59,6 +63,64 @@
 #endif
 
 namespace {
+
+// ---- backward hand-off tiles as PRE-SPLIT bf16 planes (round 2, with the XCD-local stores).  The producer
+// splits its dWx values once (x = t1 + t2 + t3, truncation split) and publishes the three planes; a consumer
+// loads MFMA fragments and nothing else: 6 KB per tile instead of 4, no split VALU in the 32 consumers (each of
+// which used to split the same 32 x 1024 values: 2.8 k VALU cycles per SIMD and step).  Tile layout: 16-byte
+// piece ((ks*3 + p)*64 + h*32 + row) = plane p, k = 16 ks + 8 h + 0..7 of that row — the wave-load of one
+// (k16-step, plane) is one contiguous 1 KiB.  A producer thread owns 4 consecutive k: half a piece, written
+// with 8-byte stores (first / last word of a piece sit in different halves: the sentinel check covers both).
+// No plane word can equal the sentinel: its upper half would be a signalling-NaN bf16, and every plane value
+// is the upper half of an arithmetic fp32 result.
+constexpr int PTILE_BYTES = RT * CT * 6;
+template <int NW>
+__device__ __forceinline__ void issue_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg, int n_ct) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned off = kg < n_ct ? base + (unsigned)kg * PTILE_BYTES + (unsigned)((ks * 3 + p) * 1024) : 0xFFFFFF00u;
+            g[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
+        }
+}
+__device__ __forceinline__ void settle_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base, int* abort_slot) {
+    unsigned miss = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) miss |= piece_missing(g[ks][p]) ? (1u << (ks * 3 + p)) : 0u;
+    if (__any(miss != 0)) {  // slow path as settle_tile: temporaries, builtin wait, merge by select
+        const u64 t_start = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            u32x4 tmp[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    tmp[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * 3 + p) * 1024), 0, REC_LD_AUX);
+            vm_settled();
+            unsigned still = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned bit = 1u << (ks * 3 + p);
+                    const bool m = (miss & bit) != 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[ks][p][e] = m ? tmp[ks][p][e] : g[ks][p][e];
+                    if (m && piece_missing(tmp[ks][p])) still |= bit;
+                }
+            miss = still;
+            if (!__any(miss != 0)) break;
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                *(volatile int*)abort_slot = 1;
+                break;
+            }
+        }
+    }
+}
 
 struct RecArgs {
     int B, dirs, T, H, Bp;
@@ -480,9 +542,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
     // hand-off ring: ring[slot][rt][ct] = one 4 KiB fp32 tile in fragment order; one buffer resource
-    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * TILE_BYTES);
+    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * PTILE_BYTES);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
-    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
+    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * PTILE_BYTES);
 
     const bool drop = a.p_drop > 0.0f;
     const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
@@ -531,9 +593,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // 9.7 k cycles against 10.2 k: the phase is throughput-, not hand-off-latency-bound — L2 port
             // 3.7 k, and MFMA (3.1 k) + split VALU (2.8 k) add up on the SIMD instead of overlapping.
             constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;
-            u32x4 raw[KGW][2][2];
+            u32x4 raw[KGW][2][3];  // [k-group][k16-step][plane]: MFMA A fragments as they come off the wire
 #pragma unroll
-            for (int kk = 0; kk < AHEAD; ++kk) issue_tile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
+            for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             PROF_STAMP(0);  // first tile load issue
             f32x16 acc;
 #pragma unroll
@@ -544,41 +606,24 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 // (scheduling barriers: hipcc otherwise hoists the next group's check, and its wait, into this
                 // group's MFMAs)
                 __builtin_amdgcn_sched_barrier(0);
-                settle_tile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * TILE_BYTES, &abort_flag[par]);
-                if (kk + AHEAD < KGW) issue_tile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
+                settle_ptile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * PTILE_BYTES, &abort_flag[par]);
+                if (kk + AHEAD < KGW) issue_ptile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
                 __builtin_amdgcn_sched_barrier(0);
-                {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        // exact truncation split of the 8 fp32 values into three bf16 fragments
-                        u32x4 p1, p2, p3;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {
-                                const unsigned x0 = raw[kk][ks][q][2 * pr], x1 = raw[kk][ks][q][2 * pr + 1];
-                                const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
-                                const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
-                                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
-                                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
-                                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
-                                p1[2 * q + pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-                                p2[2 * q + pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
-                                p3[2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-                            }
-                        const u32x4 vl = vlo[wave][kk][ks][lane];
-                        // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first.  Dropped:
-                        // t3*mid (|t3| < 2^-14 |x| after two 8-bit truncations, |V_mid| <= 2^-8 |V|: <= 2^-22 of
-                        // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
-                        // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
-                        // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
-                        acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
-                        acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
-                        acc = mfma_bf16(p1, vl, acc);             // t1*lo
-                        acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
-                        acc = mfma_bf16(p1, vb[kk][ks][1], acc);  // t1*mid
-                        acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
-                    }
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4 p1 = raw[kk][ks][0], p2 = raw[kk][ks][1], p3 = raw[kk][ks][2];
+                    const u32x4 vl = vlo[wave][kk][ks][lane];
+                    // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first.  Dropped:
+                    // t3*mid (|t3| < 2^-14 |x| after two 8-bit truncations, |V_mid| <= 2^-8 |V|: <= 2^-22 of
+                    // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
+                    // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
+                    // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
+                    acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
+                    acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
+                    acc = mfma_bf16(p1, vl, acc);             // t1*lo
+                    acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
+                    acc = mfma_bf16(p1, vb[kk][ks][1], acc);  // t1*mid
+                    acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
                 }
             }
             float* rd = red[wave];
@@ -645,22 +690,40 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         if (EXT) {
             if (valid) st4(a.dwx_step + (size_t)bp * H + col, dwx);  // operand of the caller's dWx_t @ V^T product
         } else if (pw) {
-            const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
-            const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
+            // this thread's 4 values = k 4 cq .. +3 of its row: k16-step cq >> 2, k-half (cq >> 1) & 1, first or
+            // second 8 bytes of that piece; the three planes of a piece are 1 KiB apart
+            const unsigned piece = (unsigned)(((cq >> 2) * 3 * 64 + ((cq >> 1) & 1) * 32 + r) * 16 + (cq & 1) * 8);
+            const unsigned tile_off = rt_off + (unsigned)ct * PTILE_BYTES + piece;
             if (t > 0) {
-                u32x4 rawv;
+                u32x2 w[3];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(dwx[e]);
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned x0 = __float_as_uint(dwx[2 * pr]), x1 = __float_as_uint(dwx[2 * pr + 1]);
+                    const float r0 = dwx[2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+                    const float r1 = dwx[2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+                    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                    const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                    const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                    w[0][pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                    w[1][pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                    w[2][pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                }
                 const unsigned so = (unsigned)(t % RING) * slot_bytes + tile_off;
-                if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, so, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, so, 0, REC_ST_AUX);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
+                }
             }
 #ifndef REC_NO_RESET
             if (t + 2 < T) {
-                const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+                const u32x2 sent = {SENTINEL, SENTINEL};
                 const unsigned so = (unsigned)((t + 2) % RING) * slot_bytes + tile_off;
-                if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, so, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, so, 0, REC_ST_AUX);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
+                }
             }
 #endif
         }
@@ -1048,8 +1111,11 @@ int pick_kgw(int H) {
 size_t fwd_chan_bytes(int Bp, int T, int H) {
     return (size_t)T * cdiv(Bp, RT) * cdiv(H, CT) * 32 * sizeof(u64);
 }
-size_t bwd_ring_bytes(int Bp, int H) {
+size_t bwd_ring_bytes(int Bp, int H) {  // dense fp32 tiles (the RNN cell)
     return (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * TILE_BYTES;
+}
+size_t bwd_pring_bytes(int Bp, int H) {  // pre-split plane tiles (the spiking backward)
+    return (size_t)RING * cdiv(Bp, RT) * cdiv(H, CT) * PTILE_BYTES;
 }
 // agreement table of the XCD-local stores: one word per workgroup, behind the granules / the ring
 size_t xcd_tab_bytes(int Bp, int H) { return (size_t)cdiv(Bp, RT) * cdiv(H, CT) * sizeof(unsigned); }
@@ -1109,7 +1175,7 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
         if (hipMemsetAsync(a.chan, 0, fb + tabb, st) != hipSuccess) return SPARCH_ELAUNCH;
         a.xcd_tab = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.chan) + fb);
     } else {  // every ring piece reads "not written yet" until its producer's store lands
-        const size_t rb = bwd_ring_bytes(a.Bp, a.H);
+        const size_t rb = bwd_pring_bytes(a.Bp, a.H);
         if (hipMemsetD32Async((hipDeviceptr_t)a.chan, (int)SENTINEL, (rb + tabb) / 4, st) != hipSuccess)
             return SPARCH_ELAUNCH;
         a.ring = reinterpret_cast<char*>(a.chan);
@@ -1289,7 +1355,7 @@ extern "C" int sparch_vmask(int H, const float* V, float* vmasked, void* stream)
 extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
     // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: fp32 tile ring
-    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_ring_bytes(Bp, H);
+    const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_pring_bytes(Bp, H);
     return (f > b ? f : b) + xcd_tab_bytes(Bp, H);
 }
 
@@ -1344,7 +1410,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
     if (!al16({g_out, u_save, w_save, vpack_t, u0, w0, s0, dWx, s_prev16, dparam_ws, chan})) return SPARCH_EALIGN;
-    if (bwd_ring_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
+    if (bwd_pring_bytes(B * dirs, H) >= ((size_t)1 << 31)) return SPARCH_EINVAL;  // 32-bit buffer offsets
     RecArgs r{};
     r.B = B; r.dirs = dirs; r.T = T; r.H = H; r.Bp = B * dirs;
     r.alpha = alpha; r.beta = beta; r.a = a; r.b = b;
