@@ -821,6 +821,7 @@ struct AnnArgs {
     const float* g_out; const float* y_in;         // backward inputs (y_in = the forward's y_state)
     float* dpre; float* y_prev;                    // backward outputs
     char* ring; unsigned* status;
+    unsigned* xcd_tab;  // agreement table of the XCD-local stores (whole-sequence launches), or null
     // step variant (EXT): this ONE step's recurrent product comes from the caller (Bp,H); the step's y / dpre
     // also goes to a contiguous (Bp,H) buffer, the operand of the caller's next product
     const float* rec_ext; float* step_out;
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
     __shared__ int abort_flag[2];
+    __shared__ int xcd_local_flag;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -873,11 +875,15 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (!BWD && a.scale) { sc = ld4(a.scale + colc); sh = ld4(a.shift + colc); }
     if (tid < 2) abort_flag[tid] = 0;
+    const unsigned my_xcc = xcc_id();
+    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, SENTINEL, a.n_ct, ct, my_xcc, tid, &xcd_local_flag);
     __syncthreads();
+    const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
-    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * TILE_BYTES);
+    // hand-off tiles as pre-split bf16 planes (6 KB), as in the spiking backward
+    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * PTILE_BYTES);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
-    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * TILE_BYTES);
+    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * PTILE_BYTES);
     const bool drop = a.p_drop > 0.0f;
     const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -908,35 +914,21 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
             const unsigned slot = (unsigned)((s - 1) % RING);
             const unsigned base = slot * slot_bytes + rt_off + (unsigned)lane * 16u;
             constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;  // see rec_bwd_kernel
-            u32x4 raw[KGW][2][2];
+            u32x4 raw[KGW][2][3];  // [k-group][k16-step][plane]
 #pragma unroll
-            for (int kk = 0; kk < AHEAD; ++kk) issue_tile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
+            for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
                 __builtin_amdgcn_sched_barrier(0);
-                settle_tile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * TILE_BYTES, &abort_flag[par]);
-                if (kk + AHEAD < KGW) issue_tile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
+                settle_ptile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * PTILE_BYTES, &abort_flag[par]);
+                if (kk + AHEAD < KGW) issue_ptile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 p1, p2, p3;  // exact truncation split of the 8 fp32 values
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const unsigned x0 = raw[kk][ks][q][2 * pr], x1 = raw[kk][ks][q][2 * pr + 1];
-                            const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xFFFF0000u);
-                            const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xFFFF0000u);
-                            const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
-                            const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
-                            const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
-                            p1[2 * q + pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-                            p2[2 * q + pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
-                            p3[2 * q + pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-                        }
+                    const u32x4 p1 = raw[kk][ks][0], p2 = raw[kk][ks][1], p3 = raw[kk][ks][2];
                     const u32x4 vl = vlo[wave][kk][ks][lane];
                     acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
                     acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
@@ -995,19 +987,37 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         if (EXT) {
             if (valid) st4(a.step_out + (size_t)bp * H + col, val);
         } else if (pw) {
-            const unsigned piece = (unsigned)((((cq >> 2) * 2 + (cq & 1)) * 64 + ((cq >> 1) & 1) * 32 + r) * 16);
-            const unsigned tile_off = rt_off + (unsigned)ct * TILE_BYTES + piece;
+            const unsigned piece = (unsigned)(((cq >> 2) * 3 * 64 + ((cq >> 1) & 1) * 32 + r) * 16 + (cq & 1) * 8);
+            const unsigned tile_off = rt_off + (unsigned)ct * PTILE_BYTES + piece;
             if (s + 1 < T) {
-                u32x4 rawv;
+                u32x2 w[3];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rawv[e] = __float_as_uint(val[e]);
-                __builtin_amdgcn_raw_buffer_store_b128(rawv, rsrc, (unsigned)(s % RING) * slot_bytes + tile_off, 0,
-                                                       REC_ST_AUX);
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned x0 = __float_as_uint(val[2 * pr]), x1 = __float_as_uint(val[2 * pr + 1]);
+                    const float r0 = val[2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+                    const float r1 = val[2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+                    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                    const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                    const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                    w[0][pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                    w[1][pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                    w[2][pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                }
+                const unsigned so = (unsigned)(s % RING) * slot_bytes + tile_off;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
+                }
             }
             if (s >= 2) {
-                const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
-                __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (unsigned)((s - 2) % RING) * slot_bytes + tile_off,
-                                                       0, REC_ST_AUX);
+                const u32x2 sent = {SENTINEL, SENTINEL};
+                const unsigned so = (unsigned)((s - 2) % RING) * slot_bytes + tile_off;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
+                }
             }
         }
         lds_barrier();
@@ -1248,12 +1258,15 @@ int run_ann(int act, AnnArgs& a, void* chan, size_t chan_bytes, int steps_per_la
     a.nkg = 4 * kgw;
     a.n_rt_total = cdiv(a.Bp, RT);
     if (!chan || chan_bytes < sparch_rec_chan_bytes(a.Bp, a.T, a.H)) return SPARCH_EWORKSPACE;
-    if (hipMemsetD32Async((hipDeviceptr_t)chan, (int)SENTINEL, bwd_ring_bytes(a.Bp, a.H) / 4, st) != hipSuccess)
+    const size_t rb = bwd_pring_bytes(a.Bp, a.H), tabb = xcd_tab_bytes(a.Bp, a.H);  // plane tiles + agreement table
+    if (hipMemsetD32Async((hipDeviceptr_t)chan, (int)SENTINEL, (rb + tabb) / 4, st) != hipSuccess)
         return SPARCH_ELAUNCH;
     a.ring = reinterpret_cast<char*>(chan);
+    a.xcd_tab = reinterpret_cast<unsigned*>(a.ring + rb);
     int L = steps_per_launch;
     if (L < 1) L = 1;
     if (L > a.T) L = a.T;
+    if (L < a.T || !xcd_local_enabled()) a.xcd_tab = nullptr;  // whole-sequence launches only
     int cus = sparch_device_cus();
     if (cus <= 0) cus = 256;
     int rt_per_launch;
