@@ -22,6 +22,7 @@ USE_SPIKE_GEMM = os.environ.get("SPARCH_SPIKE_GEMM", "1") != "0"
 # spike operands travel between layers as bf16 0/1 planes next to the fp32 tensors (half the GEMM operand bytes)
 USE_SPIKE16 = os.environ.get("SPARCH_SPIKE16", "1") != "0"
 USE_PRESPLIT = os.environ.get("SPARCH_PRESPLIT", "1") != "0"  # weights split into bf16 planes once per step
+PRESPLIT_NT = os.environ.get("SPARCH_PRESPLIT_NT", "0") == "1"  # ... also for the forward projection (see SpikingLayerFn)
 
 # Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
@@ -597,12 +598,16 @@ class SpikingLayerFn(torch.autograd.Function):
         ctx.xflag = xflag
         x16 = cfg.get("in_spike16") if in_scale is not None else None
         x16 = x16.view(M, K) if x16 is not None else None
-        # the weights' bf16 planes, split once here and used by this projection and by backward's dx GEMM
+        # the weights' bf16 planes, split once here for backward's dx GEMM (775 -> 732 us).  The projection itself
+        # converts W on the fly by default: every workgroup streams all of W, and 4 MB of fp32 stay resident in
+        # the XCD's 4 MB L2 where 6 MB of planes do not (0.42 against 0.61 GB of L2 misses per launch, 1.8 % faster;
+        # SPARCH_PRESPLIT_NT=1 hands it the planes too)
         need_dx = ctx.needs_input_grad[1]
-        w_planes = split_planes(W) if (x16 is not None or need_dx) and K % 32 == 0 and H >= 128 else None
+        planes_ok = K % 32 == 0 and H >= 128
+        w_planes = split_planes(W) if planes_ok and (need_dx or (PRESPLIT_NT and x16 is not None)) else None
         ctx.w_planes = w_planes if need_dx else None
-        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale,
-                                  a_exact_flag=xflag, a16=x16, b_planes=w_planes)  # snns.py:261
+        Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale, a_exact_flag=xflag, a16=x16,
+                                  b_planes=w_planes if PRESPLIT_NT else None)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
