@@ -184,6 +184,88 @@ __device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rs
     }
 }
 
+// ---- hand-off tiles as PRE-SPLIT bf16 planes (round 2, with the XCD-local stores).  The producer
+// splits its dWx values once (x = t1 + t2 + t3, truncation split) and publishes the three planes; a consumer
+// loads MFMA fragments and nothing else: 6 KB per tile instead of 4, no split VALU in the 32 consumers (each of
+// which used to split the same 32 x 1024 values: 2.8 k VALU cycles per SIMD and step).  Tile layout: 16-byte
+// piece ((ks*3 + p)*64 + h*32 + row) = plane p, k = 16 ks + 8 h + 0..7 of that row — the wave-load of one
+// (k16-step, plane) is one contiguous 1 KiB.  A producer thread owns 4 consecutive k: half a piece, written
+// with 8-byte stores (first / last word of a piece sit in different halves: the sentinel check covers both).
+// No plane word can equal the sentinel: its upper half would be a signalling-NaN bf16, and every plane value
+// is the upper half of an arithmetic fp32 result.
+constexpr int PTILE_BYTES = RT * CT * 6;
+template <int NW>
+__device__ __forceinline__ void issue_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg, int n_ct) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned off = kg < n_ct ? base + (unsigned)kg * PTILE_BYTES + (unsigned)((ks * 3 + p) * 1024) : 0xFFFFFF00u;
+            g[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
+        }
+}
+__device__ __forceinline__ void settle_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base, int* abort_slot) {
+    unsigned miss = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) miss |= piece_missing(g[ks][p]) ? (1u << (ks * 3 + p)) : 0u;
+    if (__any(miss != 0)) {  // slow path as settle_tile: temporaries, builtin wait, merge by select
+        const u64 t_start = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            u32x4 tmp[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    tmp[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * 3 + p) * 1024), 0, REC_LD_AUX);
+            vm_settled();
+            unsigned still = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned bit = 1u << (ks * 3 + p);
+                    const bool m = (miss & bit) != 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[ks][p][e] = m ? tmp[ks][p][e] : g[ks][p][e];
+                    if (m && piece_missing(tmp[ks][p])) still |= bit;
+                }
+            miss = still;
+            if (!__any(miss != 0)) break;
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                *(volatile int*)abort_slot = 1;
+                break;
+            }
+        }
+    }
+}
+
+// exact truncation split of a thread's 4 fp32 values into three words-pairs of bf16 (plane p: w[p] = 4 bf16)
+__device__ __forceinline__ void split4_planes(const f32x4& v, u32x2 (&w)[3]) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const unsigned x0 = __float_as_uint(v[2 * pr]), x1 = __float_as_uint(v[2 * pr + 1]);
+        const float r0 = v[2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+        const float r1 = v[2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+        const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+        const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+        const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+        w[0][pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        w[1][pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+        w[2][pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+}
+// one plane-tile half piece per plane (8 bytes each, 1 KiB apart) at byte offset `off`; `plain`: XCD-local stores
+__device__ __forceinline__ void store_planes(const u32x2 (&w)[3], __amdgpu_buffer_rsrc_t rsrc, unsigned off, bool plain) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (plain) __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, off + (unsigned)(p * 1024), 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, off + (unsigned)(p * 1024), 0, REC_ST_AUX);
+    }
+}
+
 // exact truncation split of one k-group's tile (2 k16-steps x 8 fp32 values per lane) into the three bf16
 // fragments per k16-step: P[ks][0..2] = t1, t2, t3 with x = t1 + t2 + t3 (v_perm for the packing, AND + SUB for
 // the residuals: ~5.5 VALU instructions per value)
