@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = the workload's batch per GPU, strong = that batch split over the GPUs")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm over the global batch")
+    ap.add_argument("--compute-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="operand precision of the matrix products: fp32 = exact bf16 splits (the headline, default); "
+                         "bf16 = operands rounded once, fp32 accumulation and state (BASELINE.json configs[4] names bf16)")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the whole step as one captured HIP graph (sparch_amd.graph.GraphedTrainStep)")
     args = ap.parse_args()
@@ -187,6 +190,8 @@ def main():
     import sparch_amd
     from sparch_amd import dp
     from sparch_amd import functional as Fn
+    Fn.set_compute_dtype(args.compute_dtype)
+    low = Fn.compute_dtype() == "bf16"
 
     # RCCL ("nccl") is the real backend; SPARCH_DIST_BACKEND=gloo + SPARCH_SHARE_GPU=1 exist only to rehearse the
     # multi-process code path on a one-GPU box (all ranks on cuda:0)
@@ -311,10 +316,11 @@ def main():
             avg_s = kern[dom]["avg_ms"] * 1e-3
             if bound == "mfma":
                 ach = amount / avg_s / 1e12
-                roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(dom),
+                peak = PEAK_MFMA_BF16_TFLOPS if low else PEAK_MFMA_F32_TFLOPS  # bf16 mode: one bf16 MFMA per product
+                roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": None if low else pmc_traffic(dom),
                         "avg_ms": kern[dom]["avg_ms"]}
-                k6 = bf16_issue_factor(dom)
+                k6 = None if low else bf16_issue_factor(dom)
                 if k6 is not None:  # the same time priced as what the kernel really issues: bf16 MFMAs of the
                     roof["frac_bf16_pipe"] = ach * k6 / PEAK_MFMA_BF16_TFLOPS  # exact split, vs the bf16 peak
                     roof["bf16_products_per_fp32_product"] = k6
@@ -344,12 +350,14 @@ def main():
             "metric": "train-step timesteps*samples/sec (fwd+bwd+Adam), " + titles[args.workload],
             "value": value, "unit": "timesteps*samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if low else "f32", "data": "synthetic",
             "config": {"workload": f"{'bidirectional ' if bidir else ''}{w['neuron_type']} {w['layer_sizes']} batchnorm "
                                    f"pdrop={w['pdrop']}, B={B}/GPU {inp} ({origin})",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "sync_bn": bool(world > 1 and args.sync_bn),
                        "launch": "one captured HIP graph per step" if args.graph == "on" else "eager",
+                       "operands": ("rounded once to bf16, fp32 accumulation / states / updates" if low else
+                                    "fp32 through exact bf16 splits"),
                        "grad_allreduce": (None if reducer is None else
                                           ("overlapped with backward" if reducer.overlap else "one collective after backward"))},
             "roofline": roof, "cpu_baseline": cpu,

@@ -53,6 +53,21 @@ const char* sparch_last_hip_error(void);
 /* Number of compute units / XCDs the library sizes its persistent grids for. */
 int sparch_device_cus(void);
 
+/* Operand precision of every matrix product of the library: the GEMMs below and the recurrent cells'
+ * s_{t-1} @ V / dWx_{t+1} @ V^T (G3/G4).  The reference has no such switch (it is fp32-only: snns.py:29 casts the
+ * spikes to float and snns.py:572 then requires a float V); BASELINE.json configs[4] names a bf16 run.
+ *   SPARCH_PRECISION_FP32_EXACT (default): fp32 operands split exactly into bf16 planes, exact products, fp32
+ *       accumulation — fp32 results.
+ *   SPARCH_PRECISION_BF16: every fp32 operand is rounded ONCE to bf16 (nearest-even) as it is staged, one bf16
+ *       MFMA per product, fp32 accumulation; states, statistics, outputs and parameter updates stay fp32.
+ *       Spike operands (0 / 1) and bf16-representable weights lose nothing: a network whose weights are
+ *       bf16-exact has a bit-identical forward pass in both modes.
+ * Process-wide; set it between steps.  Returns SPARCH_EINVAL for an unknown mode. */
+#define SPARCH_PRECISION_FP32_EXACT 0
+#define SPARCH_PRECISION_BF16 1
+int sparch_set_operand_precision(int mode);
+int sparch_get_operand_precision(void);
+
 /* ------------------------------------------------------------------------------------
  * G1  feed-forward projection  (replaces `self.W(x)` = nn.Linear, snns.py:261/398/533/675/796,
  *     and its autograd backward).  Hand-written fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs.

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "sparch_strerror": (c_char_p, [c_int]),
     "sparch_last_hip_error": (c_char_p, []),
     "sparch_device_cus": (c_int, []),
+    "sparch_set_operand_precision": (c_int, [c_int]),
+    "sparch_get_operand_precision": (c_int, []),
     "sparch_gemm_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
     "sparch_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -7,7 +7,19 @@ void sparch_note_hip_error(int e) { g_last_hip_error = e; }
 // 2: bf16 spike planes (s16_out, s_prev16, spike16 GEMMs), adam
 // 3: step variants of the recurrent cells (any hidden size), BatchNorm sums out of the cell backward kernels,
 //    optional bf16 saved states, device-side skip words on adam / bn_finalize, readout up to 256 classes
-extern "C" int sparch_abi_version(void) { return 3; }
+// 4: sparch_set_operand_precision (bf16 operands, fp32 accumulation) for the GEMMs and the recurrent cells
+extern "C" int sparch_abi_version(void) { return 4; }
+
+// Process-wide operand precision of every matrix product of the library (GEMMs and the recurrent cells'
+// s @ V / dWx @ V^T): set between steps, never while launches are being enqueued from another thread.
+static int g_operand_precision = SPARCH_PRECISION_FP32_EXACT;
+int sparch_operand_bf16(void) { return g_operand_precision == SPARCH_PRECISION_BF16; }
+extern "C" int sparch_set_operand_precision(int mode) {
+    if (mode != SPARCH_PRECISION_FP32_EXACT && mode != SPARCH_PRECISION_BF16) return SPARCH_EINVAL;
+    g_operand_precision = mode;
+    return SPARCH_OK;
+}
+extern "C" int sparch_get_operand_precision(void) { return g_operand_precision; }
 
 extern "C" const char* sparch_last_hip_error(void) {
     return hipGetErrorString((hipError_t)g_last_hip_error);

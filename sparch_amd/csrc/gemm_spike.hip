@@ -253,6 +253,21 @@ __device__ __forceinline__ void store_piece(const f32x4& r, int p, unsigned shor
         *reinterpret_cast<u32x2*>(S + 2 * PLANE + off) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
     }
 }
+// ---- the bf16 operand mode (sparch_set_operand_precision): ONE plane, each fp32 value rounded to nearest-even
+// (v_cvt_pk_bf16_f32 on gfx950)
+template <bool KM, int ROWS, int NT>
+__device__ __forceinline__ void store_piece_rne1(const f32x4& r, int p, unsigned short* __restrict__ S, int tid) {
+    constexpr int RQ = ROWS / 4;
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const int f = tid + NT * p;
+    int off;
+    if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
+    else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
+    u32x2 w;
+    w.x = __builtin_bit_cast(unsigned, bf16x2{(__bf16)r.x, (__bf16)r.y});
+    w.y = __builtin_bit_cast(unsigned, bf16x2{(__bf16)r.z, (__bf16)r.w});
+    *reinterpret_cast<u32x2*>(S + off) = w;
+}
 // ---- MFMA fragment (8 bf16 of row/col `idx`, k = 16*ks + 8*h + j) from an LDS plane
 template <bool KM, int ROWS>
 __device__ __forceinline__ u32x4 frag_read(const unsigned short* __restrict__ S, int idx_base, int lane, int ks) {
@@ -317,10 +332,10 @@ template <int MODE, bool FAST, bool BIG = false> struct Shape {
 
 extern __shared__ __attribute__((aligned(16))) unsigned short dyn_lds[];
 
-template <bool A_KM, bool B_KM, int MODE, bool FAST>
+template <bool A_KM, bool B_KM, int MODE, bool FAST, int NP = 3>
 constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of both operand tiles)
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
-    return (MODE == 0 ? 1 : 3) * plane_elems<A_KM, S::BM>() + (MODE == 1 ? 1 : 3) * plane_elems<B_KM, S::BN>();
+    return (MODE == 0 ? 1 : NP) * plane_elems<A_KM, S::BM>() + (MODE == 1 ? 1 : NP) * plane_elems<B_KM, S::BN>();
 }
 
 // FAST: one workgroup per CU (one wave per SIMD, up to 512 registers), TWO LDS stages, and the whole
@@ -331,18 +346,21 @@ constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of 
 // phase, barrier — the matrix pipe was busy 47 % of the time: neither workgroup's latency chain was
 // short enough for two to cover each other.)
 // !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false>
+// NP: planes of a dense operand — 3 = the exact split (default), 1 = the bf16 operand mode (one rounding, one
+// MFMA per product; MODE 2 then has ONE term).
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3>
 __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
     static_assert(!S16 || MODE != 2, "a bf16 plane is a spike operand");
     static_assert(!BPRE || (FAST && MODE != 1), "pre-split B: pipelined kernel, B is the dense operand");
+    static_assert(NP == 3 || (NP == 1 && !BPRE), "dense operands: three exact planes or one rounded plane");
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
     constexpr int WI = S::WI, WJ = S::WJ, WN = S::WN, BM = S::BM, BN = S::BN, NT = S::NT;
-    constexpr int A_PLANES = SPIKE_A ? 1 : 3;
-    [[maybe_unused]] constexpr int B_PLANES = SPIKE_B ? 1 : 3;
+    constexpr int A_PLANES = SPIKE_A ? 1 : NP;
+    [[maybe_unused]] constexpr int B_PLANES = SPIKE_B ? 1 : NP;
     constexpr int PLANE_A = plane_elems<A_KM, BM>(), PLANE_B = plane_elems<B_KM, BN>();
-    constexpr int STAGE = stage_elems<A_KM, B_KM, MODE, FAST>();
+    constexpr int STAGE = stage_elems<A_KM, B_KM, MODE, FAST, NP>();
     unsigned short* const lds = dyn_lds;  // [FAST ? 2 : 1][A planes | B planes]
 
     if (g.gate != nullptr && *g.gate != g.gate_want) return;  // uniform: every workgroup reads the same word
@@ -402,11 +420,13 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     auto convert_piece = [&](auto& ra, auto& rb, int q, unsigned short* st) __attribute__((always_inline)) {
         if (q < NPA) {
             if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
+            else if constexpr (NP == 1 && !SPIKE_A) store_piece_rne1<A_KM, BM, NT>(ra[q], q, st, tid);
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
         } else if (q < NPA + NPB) {
             if constexpr (BPRE)  // plane (q - NPA) / NPB1 straight into its LDS image: no conversion
                 store_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, st + A_PLANES * PLANE_A + ((q - NPA) / NPB1) * PLANE_B, tid);
             else if constexpr (B16) store_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
+            else if constexpr (NP == 1 && !SPIKE_B) store_piece_rne1<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
             else store_piece<B_KM, BN, NT, SPIKE_B, true>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid, g.e_exact);
         }
     };
@@ -441,7 +461,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     GP_DECL
     constexpr int WS = SPIKE_A ? WI : WJ, WD = SPIKE_A ? WJ : WI;   // spike-side / dense-side tiles per wave
     constexpr int SB = FAST ? 2 : 1;
-    [[maybe_unused]] u32x4 fa[MODE == 2 ? 2 : 1][MODE == 2 ? WI : 1][3], fb[MODE == 2 ? 2 : 1][MODE == 2 ? WJ : 1][3];
+    [[maybe_unused]] u32x4 fa[MODE == 2 ? 2 : 1][MODE == 2 ? WI : 1][NP], fb[MODE == 2 ? 2 : 1][MODE == 2 ? WJ : 1][NP];
     [[maybe_unused]] u32x4 fs[MODE != 2 ? SB : 1][MODE != 2 ? WS : 1], fd[2][MODE != 2 ? WD : 1];
     // MODE 2: all fragments of a 16-deep k step, double buffered across the two steps
     auto read_step = [&](const unsigned short* st, int ks) __attribute__((always_inline)) {
@@ -450,12 +470,12 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
 #pragma unroll
         for (int i = 0; i < WI; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 fb[ks][j][p] = frag_read<B_KM, BN>(Bs + p * PLANE_B, (wn * WJ + j) * 32, lane, ks);
     };
     // MODE 0 / 1: dense fragments double buffered by group, spike fragments by k step (the general kernel's
@@ -479,13 +499,14 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     // the fragments of a phase's first group, from the stage it will run on
     auto pre_read = [&](const unsigned short* st) __attribute__((always_inline)) {
         if constexpr (MODE == 2) read_step(st, 0);
-        else { read_spike(st, 0); read_dense(st, 0, 0, 2); }
+        else { read_spike(st, 0); read_dense(st, 0, 0, NP - 1); }
     };
     auto mfma_phase = [&](const unsigned short* cur, const unsigned short* nxt, auto has_next, auto side)
                           __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
-        constexpr int NG = MODE == 2 ? 12 : 6;              // MFMA groups of WI x WJ per K tile
-        constexpr int TAIL = !HAS_NEXT ? 0 : (MODE == 2 ? GEMM_TAIL2 : 1);  // groups behind the barrier
+        constexpr int NTERM = NP == 3 ? 6 : 1;              // cross terms of a dense x dense product
+        constexpr int NG = MODE == 2 ? 2 * NTERM : 2 * NP;  // MFMA groups of WI x WJ per K tile
+        constexpr int TAIL = !HAS_NEXT ? 0 : (MODE == 2 && NP == 3 ? GEMM_TAIL2 : 1);  // groups behind the barrier
         constexpr int PPG = (NPA + NPB + NG - TAIL - 1) / (NG - TAIL);
         auto handover = [&]() __attribute__((always_inline)) {
             GP_STAMP(3);  // MFMA groups with the next tile's conversion and the loads after it
@@ -496,13 +517,13 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         if constexpr (MODE == 2) {
             // both operands dense: six cross terms per 16-deep k step; a group = one term
             // (pa, pb) pairs, small terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
-            constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
-            constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+            constexpr int PA[6] = {NP == 3 ? 1 : 0, 2, 0, 1, 0, 0};
+            constexpr int PB[6] = {NP == 3 ? 1 : 0, 0, 2, 0, 1, 0};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const int gi = ks * 6 + c;
+                for (int c = 0; c < NTERM; ++c) {
+                    const int gi = ks * NTERM + c;
                     if (gi == 0) read_step(cur, 1);
                     if (HAS_NEXT && gi == NG - TAIL) handover();
                     if (gi < NG - TAIL) {
@@ -520,10 +541,10 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         } else {
             // one spike-side plane, three dense-side planes: a group = one plane of one k step
 #pragma unroll
-            for (int gi = 0; gi < 6; ++gi) {
-                const int ks = gi / 3, p = 2 - gi % 3;  // smallest plane first
+            for (int gi = 0; gi < NG; ++gi) {
+                const int ks = gi / NP, p = NP - 1 - gi % NP;  // smallest plane first
                 if (p > 0) read_dense(cur, (gi + 1) & 1, ks, p - 1);
-                else if (ks == 0) { if constexpr (SB == 2) read_spike(cur, 1); read_dense(cur, (gi + 1) & 1, 1, 2); }
+                else if (ks == 0) { if constexpr (SB == 2) read_spike(cur, 1); read_dense(cur, (gi + 1) & 1, 1, NP - 1); }
                 if (HAS_NEXT && gi == NG - TAIL) handover();
                 if (gi < NG - TAIL) {
 #pragma unroll
@@ -734,7 +755,7 @@ bool fast_ok(const SArgs& g) {
            g.k_per_split >= 8 * BK;  // a short K range never fills the pipeline: general kernel, 2 workgroups per CU
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
     using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
     const int work = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
@@ -744,8 +765,8 @@ int launch_variant(SArgs& g, int splits, hipStream_t st) {
     static const bool persistent = [] { const char* e = getenv("SPARCH_GEMM_PERSISTENT"); return !e || atoi(e) != 0; }();
     const int cus = target_wgs(1);
     const int wgs = (FAST && !(A_KM && B_KM && MODE != 2) && persistent && work > cus) ? cus : work;
-    constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST>() * sizeof(unsigned short);
-    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE>;
+    constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST, NP>() * sizeof(unsigned short);
+    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE, NP>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
@@ -756,6 +777,11 @@ int launch_variant(SArgs& g, int splits, hipStream_t st) {
 
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16 = false>
 int launch(SArgs& g, int splits, hipStream_t st) {
+    if (sparch_operand_bf16()) {  // bf16 operand mode: the same kernels with ONE rounded plane per dense operand
+        if (fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
+            return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, false, 1>(g, splits, st);
+        return launch_variant<A_KM, B_KM, MODE, EPI, false, S16, false, 1>(g, splits, st);
+    }
     if (fast_ok<A_KM, B_KM, MODE, EPI, S16>(g)) return launch_variant<A_KM, B_KM, MODE, EPI, true, S16>(g, splits, st);
     return launch_variant<A_KM, B_KM, MODE, EPI, false, S16>(g, splits, st);
 }
@@ -765,7 +791,7 @@ template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16 = false>
 int launch_wp(SArgs& g, int splits, hipStream_t st) {
     const bool planes_ok = g.Bp != nullptr && aligned16(g.Bp) && g.ldb % 8 == 0 && (g.bp_stride % 8) == 0 &&
                            g.k_per_split % BK == 0 && g.K % BK == 0 && (!B_KM || g.N % 8 == 0);
-    if (planes_ok && fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
+    if (planes_ok && !sparch_operand_bf16() && fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
         return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, true>(g, splits, st);
     return launch<A_KM, B_KM, MODE, EPI, S16>(g, splits, st);
 }

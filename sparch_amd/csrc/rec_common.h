@@ -101,9 +101,10 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
-// V (or V^T) slice -> registers: per k-group, 2 k16-steps x 3 planes of 8 bf16 (4 VGPRs) each
-template <int KGW, int NW>
-__device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4* __restrict__ vpack, int ct,
+// V (or V^T) slice -> registers: per k-group, 2 k16-steps x NP planes of 8 bf16 (4 VGPRs) each (the packed
+// layout always has room for three planes; the bf16 operand mode keeps its one rounded plane in plane 0)
+template <int KGW, int NW, int NP = 3>
+__device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][NP], const u32x4* __restrict__ vpack, int ct,
                                             int nkg, int wave, int lane) {
 #pragma unroll
     for (int kk = 0; kk < KGW; ++kk) {
@@ -111,7 +112,7 @@ __device__ __forceinline__ void load_vslice(u32x4 (&vb)[KGW][2][3], const u32x4*
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 vb[kk][ks][p] = vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane];
     }
 }
@@ -193,40 +194,45 @@ __device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rs
 // with 8-byte stores (first / last word of a piece sit in different halves: the sentinel check covers both).
 // No plane word can equal the sentinel: its upper half would be a signalling-NaN bf16, and every plane value
 // is the upper half of an arithmetic fp32 result.
-constexpr int PTILE_BYTES = RT * CT * 6;
-template <int NW>
-__device__ __forceinline__ void issue_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg, int n_ct) {
+// NP planes per tile: 3 = the exact split, 1 = the bf16 operand mode (one nearest-even rounding by the producer,
+// 2 KB per tile; the same layout with NP in place of 3).  A rounded plane word cannot equal the sentinel either:
+// v_cvt_pk_bf16_f32 quiets every NaN it converts.
+constexpr int PTILE_BYTES = RT * CT * 6;  // what the host sizes the ring for (three planes)
+template <int NP> constexpr int ptile_bytes() { return RT * CT * 2 * NP; }
+template <int NW, int NP = 3>
+__device__ __forceinline__ void issue_ptile(u32x4 (&g)[2][NP], __amdgpu_buffer_rsrc_t rsrc, unsigned base, int kg, int n_ct) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const unsigned off = kg < n_ct ? base + (unsigned)kg * PTILE_BYTES + (unsigned)((ks * 3 + p) * 1024) : 0xFFFFFF00u;
+        for (int p = 0; p < NP; ++p) {
+            const unsigned off = kg < n_ct ? base + (unsigned)kg * ptile_bytes<NP>() + (unsigned)((ks * NP + p) * 1024) : 0xFFFFFF00u;
             g[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, REC_LD_AUX);
         }
 }
-__device__ __forceinline__ void settle_ptile(u32x4 (&g)[2][3], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base, int* abort_slot) {
+template <int NP = 3>
+__device__ __forceinline__ void settle_ptile(u32x4 (&g)[2][NP], __amdgpu_buffer_rsrc_t rsrc, unsigned tile_base, int* abort_slot) {
     unsigned miss = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) miss |= piece_missing(g[ks][p]) ? (1u << (ks * 3 + p)) : 0u;
+        for (int p = 0; p < NP; ++p) miss |= piece_missing(g[ks][p]) ? (1u << (ks * NP + p)) : 0u;
     if (__any(miss != 0)) {  // slow path as settle_tile: temporaries, builtin wait, merge by select
         const u64 t_start = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 0;; ++spins) {
             __builtin_amdgcn_s_sleep(1);
-            u32x4 tmp[2][3];
+            u32x4 tmp[2][NP];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    tmp[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * 3 + p) * 1024), 0, REC_LD_AUX);
+                for (int p = 0; p < NP; ++p)
+                    tmp[ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tile_base + (unsigned)((ks * NP + p) * 1024), 0, REC_LD_AUX);
             vm_settled();
             unsigned still = 0;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const unsigned bit = 1u << (ks * 3 + p);
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned bit = 1u << (ks * NP + p);
                     const bool m = (miss & bit) != 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[ks][p][e] = m ? tmp[ks][p][e] : g[ks][p][e];

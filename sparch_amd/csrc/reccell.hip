@@ -118,7 +118,8 @@ __device__ u64 g_rec_prof[2][512][8];
 // NW waves per workgroup, each taking the k-groups kg = wave + NW*kk of the contraction (partial tiles
 // summed through LDS); NW = 8 puts two waves on each SIMD so that one's LUT reads / poll latency sit
 // under the other's MFMAs.  Pointwise update, publish and stores stay on the first 256 threads.
-template <bool ADAPT, int KGW, int NW, bool EXT = false>
+// NP: planes of V — 3 = exact split (default), 1 = the bf16 operand mode (V rounded once by the pack kernel).
+template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3>
 __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    u32x4 vb[KGW][2][3];
-    if (!EXT) load_vslice<KGW, NW>(vb, a.vpack, ct, a.nkg, wave, lane);
+    u32x4 vb[KGW][2][NP];
+    if (!EXT) load_vslice<KGW, NW, NP>(vb, a.vpack, ct, a.nkg, wave, lane);
     if (pw) {
         u32x4 e;
 #pragma unroll
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int p = 2; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
+                    for (int p = NP - 1; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
             float* rd = red[t & 1][wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -383,14 +384,16 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 // per step a SIMD has 112 MFMAs, ~770 VALU instructions of splitting and 32 tile loads to issue, and with
 // a single wave those queue behind each other (and behind the first load's latency); two waves fill each
 // other's stalls.  The pointwise reverse step and the stores stay on the first 256 threads.
-template <bool ADAPT, int KGW, int NW, bool EXT = false>
+// NP: planes of the hand-off tiles and of V^T — 3 = exact split, six cross terms (default); 1 = the bf16 operand
+// mode: the producer rounds its dWx once, 2 KB tiles, ONE MFMA per k16-step.
+template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3>
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
     // waves, which reach the second (publish) barrier only when done with them -> one buffer
     __shared__ __attribute__((aligned(16))) float red[NW][RT * RED_LD];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
-    __shared__ __attribute__((aligned(16))) u32x4 vlo[NW][KGW][2][64];
+    __shared__ __attribute__((aligned(16))) u32x4 vlo[NP == 3 ? NW : 1][NP == 3 ? KGW : 1][2][64];
     // per-thread neuron constants (alpha, beta, a, b, rate gradient of the thread's 4 columns): kept in LDS
     // and re-read each step — the 8-wave kernel's 256-register budget has no room to hold them
     __shared__ __attribute__((aligned(16))) f32x4 pconst[7][256];  // + BatchNorm mean, invstd of the columns
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    u32x4 vb[KGW][2][2];
+    u32x4 vb[KGW][2][NP == 3 ? 2 : 1];
 #pragma unroll
     for (int kk = 0; kk < (EXT ? 0 : KGW); ++kk) {
         const int kg = wave + NW * kk;
@@ -429,8 +432,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         for (int ks = 0; ks < 2; ++ks) {
             const u32x4* src = a.vpack + ((((size_t)ct * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
             vb[kk][ks][0] = src[0];
-            vb[kk][ks][1] = src[64];
-            vlo[wave][kk][ks][lane] = src[128];
+            if constexpr (NP == 3) {
+                vb[kk][ks][1] = src[64];
+                vlo[wave][kk][ks][lane] = src[128];
+            }
         }
     }
 
@@ -484,9 +489,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
     // hand-off ring: ring[slot][rt][ct] = one 4 KiB fp32 tile in fragment order; one buffer resource
-    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * PTILE_BYTES);
+    constexpr unsigned PT = (unsigned)ptile_bytes<NP>();  // bytes of one hand-off tile
+    const unsigned slot_bytes = (unsigned)((size_t)a.n_rt_total * a.n_ct * PT);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, (int)(RING * slot_bytes), 0x00020000);
-    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * PTILE_BYTES);
+    const unsigned rt_off = (unsigned)((size_t)rt * a.n_ct * PT);
 
     const bool drop = a.p_drop > 0.0f;
     const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
@@ -535,9 +541,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // 9.7 k cycles against 10.2 k: the phase is throughput-, not hand-off-latency-bound — L2 port
             // 3.7 k, and MFMA (3.1 k) + split VALU (2.8 k) add up on the SIMD instead of overlapping.
             constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;
-            u32x4 raw[KGW][2][3];  // [k-group][k16-step][plane]: MFMA A fragments as they come off the wire
+            u32x4 raw[KGW][2][NP];  // [k-group][k16-step][plane]: MFMA A fragments as they come off the wire
 #pragma unroll
-            for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
+            for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW, NP>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             PROF_STAMP(0);  // first tile load issue
             f32x16 acc;
 #pragma unroll
@@ -548,24 +554,28 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 // (scheduling barriers: hipcc otherwise hoists the next group's check, and its wait, into this
                 // group's MFMAs)
                 __builtin_amdgcn_sched_barrier(0);
-                settle_ptile(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * PTILE_BYTES, &abort_flag[par]);
-                if (kk + AHEAD < KGW) issue_ptile<NW>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
+                settle_ptile<NP>(raw[kk], rsrc, base + (unsigned)(wave + NW * kk) * PT, &abort_flag[par]);
+                if (kk + AHEAD < KGW) issue_ptile<NW, NP>(raw[kk + AHEAD], rsrc, base, wave + NW * (kk + AHEAD), a.n_ct);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const u32x4 p1 = raw[kk][ks][0], p2 = raw[kk][ks][1], p3 = raw[kk][ks][2];
+                    if constexpr (NP == 1) {  // bf16 operand mode: bf16(dWx) x bf16(V^T), one product
+                        acc = mfma_bf16(raw[kk][ks][0], vb[kk][ks][0], acc);
+                    } else {
+                    const u32x4 p1 = raw[kk][ks][0], p2 = raw[kk][ks][NP - 2], p3 = raw[kk][ks][NP - 1];
                     const u32x4 vl = vlo[wave][kk][ks][lane];
                     // six largest cross terms of (t1+t2+t3)(V_hi+V_mid+V_lo), small first.  Dropped:
                     // t3*mid (|t3| < 2^-14 |x| after two 8-bit truncations, |V_mid| <= 2^-8 |V|: <= 2^-22 of
                     // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
                     // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
                     // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
-                    acc = mfma_bf16(p2, vb[kk][ks][1], acc);  // t2*mid
+                    acc = mfma_bf16(p2, vb[kk][ks][NP == 3], acc);  // t2*mid
                     acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
                     acc = mfma_bf16(p1, vl, acc);             // t1*lo
                     acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
-                    acc = mfma_bf16(p1, vb[kk][ks][1], acc);  // t1*mid
+                    acc = mfma_bf16(p1, vb[kk][ks][NP == 3], acc);  // t1*mid
                     acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
+                    }
                 }
             }
             float* rd = red[wave];
@@ -634,10 +644,15 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         } else if (pw) {
             // this thread's 4 values = k 4 cq .. +3 of its row: k16-step cq >> 2, k-half (cq >> 1) & 1, first or
             // second 8 bytes of that piece; the three planes of a piece are 1 KiB apart
-            const unsigned piece = (unsigned)(((cq >> 2) * 3 * 64 + ((cq >> 1) & 1) * 32 + r) * 16 + (cq & 1) * 8);
-            const unsigned tile_off = rt_off + (unsigned)ct * PTILE_BYTES + piece;
+            const unsigned piece = (unsigned)(((cq >> 2) * NP * 64 + ((cq >> 1) & 1) * 32 + r) * 16 + (cq & 1) * 8);
+            const unsigned tile_off = rt_off + (unsigned)ct * PT + piece;
             if (t > 0) {
                 u32x2 w[3];
+                if constexpr (NP == 1) {  // one nearest-even rounding (v_cvt_pk_bf16_f32)
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    w[0].x = __builtin_bit_cast(unsigned, bf16x2{(__bf16)dwx[0], (__bf16)dwx[1]});
+                    w[0].y = __builtin_bit_cast(unsigned, bf16x2{(__bf16)dwx[2], (__bf16)dwx[3]});
+                } else {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const unsigned x0 = __float_as_uint(dwx[2 * pr]), x1 = __float_as_uint(dwx[2 * pr + 1]);
@@ -650,9 +665,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     w[1][pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
                     w[2][pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
                 }
+                }
                 const unsigned so = (unsigned)(t % RING) * slot_bytes + tile_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
                 }
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 const u32x2 sent = {SENTINEL, SENTINEL};
                 const unsigned so = (unsigned)((t + 2) % RING) * slot_bytes + tile_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, REC_ST_AUX);
                 }
@@ -982,7 +998,13 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
 // vpack[ct][kg][ks][p][lane] = 8 bf16 (16 B): plane p (0 hi, 1 mid, 2 lo) of Vm[k][col] (forward) or
 // Vm[col][k] (backward) for k = kg*32 + 16*ks + 8*(lane>>5) + j, j = 0..7, col = ct*32 + (lane&31);
 // Vm = V with a zero diagonal, zero padded.  This is the B-operand fragment of v_mfma_f32_32x32x16_bf16.
-__global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const float* __restrict__ V,
+// rne (the bf16 operand mode): plane 0 = V rounded once to bf16, planes 1 and 2 = 0 — the kernels of that mode
+// read plane 0 only, and any three-plane kernel given such a pack computes the same bf16 products.
+__device__ __forceinline__ void vsplit(float v, int rne, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    split3(v, hi, mid, lo);
+    if (rne) { mid = 0; lo = 0; }
+}
+__global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, int rne, const float* __restrict__ V,
                              u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_ct * nkg * 2 * 64;
@@ -997,7 +1019,7 @@ __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const floa
         const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
         float v = 0.f;
         if (k < H && col < H && (keep_diag || k != col)) v = tr ? V[(size_t)col * H + k] : V[(size_t)k * H + col];
-        split3(v, pl[0][j], pl[1][j], pl[2][j]);
+        vsplit(v, rne, pl[0][j], pl[1][j], pl[2][j]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -1009,7 +1031,7 @@ __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, const floa
 }
 // forward fragments, backward (transposed) fragments and the masked copy of a spiking layer's V in ONE launch (a
 // training step needs all three; three launches were ~25 us of launch + queue gaps per layer)
-__global__ void vpack_both_kernel(int H, int n_ct, int nkg, const float* __restrict__ V, u32x4* __restrict__ vpack_f,
+__global__ void vpack_both_kernel(int H, int n_ct, int nkg, int rne, const float* __restrict__ V, u32x4* __restrict__ vpack_f,
                                   u32x4* __restrict__ vpack_b, float* __restrict__ Vm) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_ct * nkg * 2 * 64;
@@ -1022,8 +1044,8 @@ __global__ void vpack_both_kernel(int H, int n_ct, int nkg, const float* __restr
         for (int j = 0; j < 8; ++j) {
             const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
             const bool in = k < H && col < H && k != col;
-            split3(in ? V[(size_t)k * H + col] : 0.f, pf[0][j], pf[1][j], pf[2][j]);
-            split3(in ? V[(size_t)col * H + k] : 0.f, pb[0][j], pb[1][j], pb[2][j]);
+            vsplit(in ? V[(size_t)k * H + col] : 0.f, rne, pf[0][j], pf[1][j], pf[2][j]);
+            vsplit(in ? V[(size_t)col * H + k] : 0.f, rne, pb[0][j], pb[1][j], pb[2][j]);
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -1077,12 +1099,13 @@ bool xcd_local_enabled() {
     return g_xcd_local < 0 ? env_on : g_xcd_local != 0;
 }
 
-template <bool BWD, bool ADAPT>
+// NP = 1: the bf16 operand mode (sparch_set_operand_precision) — the V pack then holds one rounded plane
+template <bool BWD, bool ADAPT, int NP = 3>
 int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
     // 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
 #define SP_LAUNCH(K, KB, NWB)                                                                        \
-    if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a); \
-    else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, KB, NWB>), dim3(grid), dim3(64 * NWB), 0, st, a);
+    if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB, false, NP>), dim3(grid), dim3(64 * NWB), 0, st, a); \
+    else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, KB, NWB, false, NP>), dim3(grid), dim3(64 * NWB), 0, st, a);
     switch (kgw) {
         case 1: SP_LAUNCH(1, 1, 4) break;
         case 2: SP_LAUNCH(2, 1, 8) break;
@@ -1095,11 +1118,11 @@ int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
     return SPARCH_OK;
 }
 
-template <bool BWD, bool ADAPT>
+template <bool BWD, bool ADAPT, int NP = 3>
 bool rec_co_resident(int kgw, unsigned grid, int cus) {
 #define SP_RES(KB, NWB) \
-    return BWD ? grid_is_co_resident<rec_bwd_kernel<ADAPT, KB, NWB>>(grid, 64 * NWB, cus) \
-               : grid_is_co_resident<rec_fwd_kernel<ADAPT, KB, NWB>>(grid, 64 * NWB, cus);
+    return BWD ? grid_is_co_resident<rec_bwd_kernel<ADAPT, KB, NWB, false, NP>>(grid, 64 * NWB, cus) \
+               : grid_is_co_resident<rec_fwd_kernel<ADAPT, KB, NWB, false, NP>>(grid, 64 * NWB, cus);
     switch (kgw) {
         case 1: SP_RES(1, 4)
         case 2: SP_RES(1, 8)
@@ -1113,6 +1136,7 @@ bool rec_co_resident(int kgw, unsigned grid, int cus) {
 template <bool BWD>
 int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipStream_t st) {
     const bool adapt = kind == SPARCH_KIND_RADLIF;
+    const bool low = sparch_operand_bf16() != 0;  // the V pack must have been made in the same mode
     const int kgw = pick_kgw(a.H);
     if (kgw == 0) return SPARCH_EINVAL;
     a.n_ct = cdiv(a.H, CT);
@@ -1148,7 +1172,8 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     }
     if (L > 1) {  // ask the runtime's occupancy calculator instead of assuming one workgroup per CU fits
         const unsigned g = (unsigned)(a.n_ct * min(rt_per_launch, a.n_rt_total));
-        const bool ok = adapt ? rec_co_resident<BWD, true>(kgw, g, cus) : rec_co_resident<BWD, false>(kgw, g, cus);
+        const bool ok = low ? (adapt ? rec_co_resident<BWD, true, 1>(kgw, g, cus) : rec_co_resident<BWD, false, 1>(kgw, g, cus))
+                            : (adapt ? rec_co_resident<BWD, true>(kgw, g, cus) : rec_co_resident<BWD, false>(kgw, g, cus));
         if (!ok) {
             if (a.save16 && !BWD) return SPARCH_EINVAL;  // bf16 saves need the whole-sequence forward launch
             L = 1; rt_per_launch = a.n_rt_total;
@@ -1162,13 +1187,15 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
         if (!BWD) {
             for (int t0 = 0; t0 < a.T; t0 += L) {
                 a.t_begin = t0; a.t_end = min(a.T, t0 + L);
-                int rc = adapt ? launch_rec<false, true>(kgw, a, grid, st) : launch_rec<false, false>(kgw, a, grid, st);
+                int rc = low ? (adapt ? launch_rec<false, true, 1>(kgw, a, grid, st) : launch_rec<false, false, 1>(kgw, a, grid, st))
+                             : (adapt ? launch_rec<false, true>(kgw, a, grid, st) : launch_rec<false, false>(kgw, a, grid, st));
                 if (rc != SPARCH_OK) return rc;
             }
         } else {
             for (int t1 = a.T; t1 > 0; t1 -= L) {
                 a.t_end = t1; a.t_begin = max(0, t1 - L);
-                int rc = adapt ? launch_rec<true, true>(kgw, a, grid, st) : launch_rec<true, false>(kgw, a, grid, st);
+                int rc = low ? (adapt ? launch_rec<true, true, 1>(kgw, a, grid, st) : launch_rec<true, false, 1>(kgw, a, grid, st))
+                             : (adapt ? launch_rec<true, true>(kgw, a, grid, st) : launch_rec<true, false>(kgw, a, grid, st));
                 if (rc != SPARCH_OK) return rc;
             }
         }
@@ -1269,7 +1296,7 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
     const int n_ct = cdiv(H, CT), nkg = 4 * kgw;
     const size_t total = (size_t)n_ct * nkg * 2 * 64;
     hipLaunchKernelGGL(vpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, H, n_ct, nkg,
-                       transpose, V, reinterpret_cast<u32x4*>(vpack));
+                       transpose, sparch_operand_bf16(), V, reinterpret_cast<u32x4*>(vpack));
     SPARCH_CHECK_LAUNCH();
     if (vmasked) {
         const size_t n = (size_t)H * H;
@@ -1287,7 +1314,7 @@ extern "C" int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float*
     const int n_ct = cdiv(H, CT), nkg = 4 * kgw;
     const size_t total = (size_t)n_ct * nkg * 2 * 64;
     hipLaunchKernelGGL(vpack_both_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, n_ct,
-                       nkg, V, reinterpret_cast<u32x4*>(vpack_fwd), reinterpret_cast<u32x4*>(vpack_bwd), vmasked);
+                       nkg, sparch_operand_bf16(), V, reinterpret_cast<u32x4*>(vpack_fwd), reinterpret_cast<u32x4*>(vpack_bwd), vmasked);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

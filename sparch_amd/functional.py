@@ -38,6 +38,31 @@ FUSE_BN_SUMS = os.environ.get("SPARCH_FUSE_BN_SUMS", "1") != "0"
 # against the fp32 path (tests/test_hip_parity.py::test_bf16_saved_states_*).  Off by default.
 SAVE_BF16 = os.environ.get("SPARCH_SAVE_DTYPE", "fp32").lower() == "bf16"
 
+# Operand precision of every matrix product (include/sparch_hip.h sparch_set_operand_precision): "fp32" = exact
+# bf16 splits of fp32 operands (default, fp32 results), "bf16" = operands rounded once to bf16, fp32
+# accumulation, fp32 states / statistics / parameter updates (BASELINE configs[4]; SPARCH_COMPUTE_DTYPE=bf16 or
+# run_exp.py --compute_dtype bf16).  Stated tolerance against the fp32 path: tests/test_hip_parity.py
+# ::test_bf16_operand_mode_*.
+COMPUTE_DTYPES = {"fp32": 0, "bf16": 1}
+
+
+def set_compute_dtype(name):
+    """Select the operand precision of the library's matrix products; returns the previous setting's name."""
+    name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16"}.get(str(name).lower(), str(name).lower())
+    if name not in COMPUTE_DTYPES:
+        raise ValueError(f"compute dtype must be one of {sorted(COMPUTE_DTYPES)}, got {name!r}")
+    prev = compute_dtype()
+    check(lib.sparch_set_operand_precision(COMPUTE_DTYPES[name]), "sparch_set_operand_precision")
+    return prev
+
+
+def compute_dtype():
+    return "bf16" if lib.sparch_get_operand_precision() == 1 else "fp32"
+
+
+if os.environ.get("SPARCH_COMPUTE_DTYPE"):
+    set_compute_dtype(os.environ["SPARCH_COMPUTE_DTYPE"])
+
 SEED_IN_MEMORY = 1 << 63  # include/sparch_hip.h SPARCH_SEED_IN_MEMORY: the seed argument carries a device address
 
 BN_MOMENTUM = 0.05  # snns.py:240

@@ -167,6 +167,81 @@ def test_gemm_spike_tn_exact_split(M, N, K, side, zd):
     assert bool(((acc.cpu().double() - ref2).abs() <= 2 * bound).all())
 
 
+@pytest.fixture
+def bf16_mode():
+    """The bf16 operand mode (sparch_set_operand_precision) for one test; fp32 restored afterwards."""
+    Fn = _Fn()
+    prev = Fn.set_compute_dtype("bf16")
+    yield Fn
+    Fn.set_compute_dtype(prev)
+
+
+def _rb(x):
+    """x rounded to bf16 (nearest-even), as fp64: what the bf16 operand mode multiplies."""
+    return x.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 70, 700), (1000, 1024, 1024), (257, 35, 1024), (2048, 520, 1000),
+                                   (64, 129, 44), (512, 256, 288)])
+def test_bf16_operand_mode_gemms(M, N, K, bf16_mode):
+    """Every GEMM entry point in the bf16 operand mode against fp64 products of the bf16-ROUNDED operands
+    (one nearest-even rounding per operand element, fp32 accumulation: |err| <= 2e-6 sum|a||b|), on shapes
+    that take the pipelined kernels and on shapes that take the general ones; spike operands lose nothing."""
+    Fn = bf16_mode
+    assert Fn.compute_dtype() == "bf16"
+    g = torch.Generator().manual_seed(5 * M + N + K)
+    c = 1.0 / 0.9
+    S = (torch.rand(M, K, generator=g) < 0.1).float() * c          # spike operand (M,K)
+    s16 = (S != 0).to(torch.bfloat16).to(DEV)
+    A = torch.randn(M, K, generator=g)                               # dense operands
+    W = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+
+    def ok(C, ref, bound, what):
+        err = (C.cpu().double() - ref).abs()
+        assert bool((err <= bound).all()), (what, float((err / bound).max()))
+
+    # NT: spikes x W^T (fp32 spikes, bf16 plane), dense x W^T, device-gated choice
+    ref = S.double() @ _rb(W).T + bias.double()
+    bound = (S.double() @ _rb(W).abs().T + bias.abs().double()) * 2e-6 + 1e-6
+    C, ws = Fn.gemm_nt(S.to(DEV), W.to(DEV), bias.to(DEV), colstat=True, spike_scale=c)
+    ok(C, ref, bound, "spike_nt")
+    nt = (M + 127) // 128
+    np.testing.assert_allclose(ws.cpu().double().view(2, nt, N)[0].sum(0).numpy(), ref.sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    C16, ws16 = Fn.gemm_nt(S.to(DEV), W.to(DEV), bias.to(DEV), colstat=True, spike_scale=c, a16=s16)
+    assert torch.equal(C16, C) and torch.equal(ws16, ws)
+    Cp, _ = Fn.gemm_nt(S.to(DEV), W.to(DEV), bias.to(DEV), spike_scale=c, a16=s16, b_planes=Fn.split_planes(W.to(DEV)))
+    assert torch.equal(Cp, C), "the pre-split planes are not used in the bf16 mode: same kernel, same result"
+    refd = _rb(A) @ _rb(W).T + bias.double()
+    boundd = (_rb(A).abs() @ _rb(W).abs().T + bias.abs().double()) * 2e-6 + 1e-6
+    Cd, _ = Fn.gemm_nt(A.to(DEV), W.to(DEV), bias.to(DEV))
+    ok(Cd, refd, boundd, "dense_nt")
+    for X, r, b in ((A, refd, boundd), ((S != 0).float(), (S != 0).double() @ _rb(W).T + bias.double(), bound)):
+        Ca, _ = Fn.gemm_nt(X.to(DEV), W.to(DEV), bias.to(DEV), a_exact_flag=Fn.flag_bf16_exact(X.to(DEV)))
+        ok(Ca, r, b, "auto_nt")
+    # NN: dense (M,N') x W (N',K'): dx = G W
+    G = torch.randn(M, N, generator=g)
+    ok(Fn.gemm_nn(G.to(DEV), W.to(DEV)), _rb(G) @ _rb(W), (_rb(G).abs() @ _rb(W).abs()) * 2e-6 + 1e-6, "dense_nn")
+    # TN over the long axis: spikes^T x dense, dense^T x spikes, dense^T x dense
+    D = torch.randn(M, N, generator=g)
+    St = (torch.rand(M, K, generator=g) < 0.1).float() * c
+    reft = St.double().T @ _rb(D)
+    boundt = (St.double().T @ _rb(D).abs()) * 2e-6 + 1e-6
+    Ct = Fn.gemm_tn(St.to(DEV), D.to(DEV), spike_side=0, spike_scale=c)
+    ok(Ct, reft, boundt, "spike_tn side 0")
+    Ct16 = Fn.gemm_tn((St != 0).to(torch.bfloat16).to(DEV), D.to(DEV), spike_side=0, spike_scale=c, spike16=True)
+    assert torch.equal(Ct16, Ct)
+    ok(Fn.gemm_tn(D.to(DEV), St.to(DEV), spike_side=1, spike_scale=c), reft.T, boundt.T, "spike_tn side 1")
+    ok(Fn.gemm_tn(A.to(DEV), D.to(DEV)), _rb(A).T @ _rb(D), (_rb(A).abs().T @ _rb(D).abs()) * 2e-6 + 1e-6, "dense_tn")
+    # bf16-exact operands: the mode changes nothing — bit-identical to the exact-split kernels
+    Wd = (torch.randint(-64, 65, (N, K), generator=g).float() / 128.0).to(DEV)
+    C_b, _ = Fn.gemm_nt(S.to(DEV), Wd, spike_scale=c, a16=s16)
+    Fn.set_compute_dtype("fp32")
+    C_f, _ = Fn.gemm_nt(S.to(DEV), Wd, spike_scale=c, a16=s16)
+    Fn.set_compute_dtype("bf16")
+    assert torch.equal(C_b, C_f)
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 1024, 1024), (640, 256, 512), (300, 136, 96), (512, 1024, 700),
                                    (257, 70, 64), (2048, 520, 1000)])
 def test_gemm_presplit_weight_planes_are_bit_identical(M, N, K):
@@ -764,6 +839,59 @@ def test_snn_dyadic_network_bit_equal_spikes_and_gradients(sp, name, monkeypatch
         assert e <= 2e-4, (k, e)
         if k.endswith("V.weight"):
             assert float(torch.diag(v.grad).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", DYADIC_CASES)
+def test_bf16_operand_mode_dyadic_network(sp, name, monkeypatch, bf16_mode):
+    """The bf16 operand mode (BASELINE configs[4]; the reference is fp32-only, SURVEY §7-6: compared with the fp32
+    reference under a stated tolerance) on the fully dyadic fixtures.  Their W / V (multiples of 2^-6, |k| < 256)
+    are bf16-representable and spikes are 0 / 1, so the rounding of the mode changes NOTHING in the forward pass:
+    spikes bit-equal to the reference's through every layer, output and loss as in fp32.  The backward pass
+    rounds dWx once per matrix product (2^-9 relative per operand element, fp32 accumulation): every parameter
+    gradient within 2e-2 of its max-abs of the reference's."""
+    assert bf16_mode.compute_dtype() == "bf16"
+    cfg, z, rec, out, loss, net = _run_dyadic(sp, name, monkeypatch)
+    for k in sorted(rec):
+        ref = layer_spikes(z, k)
+        got = rec[k].cpu().numpy()
+        assert np.array_equal(got, ref), (k, float((got != ref).mean()))
+    assert np.abs(out.detach().cpu().numpy() - z["out"]).max() <= 2e-5 * cfg["T"]
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5 * max(1.0, abs(float(z["loss"])))
+    worst = 0.0
+    for k, v in net.named_parameters():
+        e = relmax(v.grad.cpu().numpy(), z["grad." + k])
+        worst = max(worst, e)
+        assert e <= 2e-2, (k, e)
+        if k.endswith("V.weight"):
+            assert float(torch.diag(v.grad).abs().max()) == 0.0
+    print(f"{name}: worst gradient relmax in the bf16 operand mode {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
+@pytest.mark.parametrize("spl", [1, None])
+def test_bf16_operand_mode_recurrent_cell(kind, spl, bf16_mode):
+    """The recurrent cell kernels of the bf16 operand mode (whole-sequence persistent launch and one launch per
+    step).  With a dyadic (bf16-exact) V the forward is the fp32 one bit for bit; the backward's hand-off tiles
+    carry bf16(dWx) (one nearest-even rounding per element per step), so its gradients are compared with oracle
+    autograd at 2e-2 of max-abs; dV's diagonal stays exactly zero."""
+    Fn = bf16_mode
+    Wx, p, u0, w0, s0, gs = _dyadic_cell_case(kind, 40, 29, 132, 5)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    Wx.requires_grad_(True)
+    ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+    (ref * gs).sum().backward()
+    pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in p.items()}
+    Wxd = Wx.detach().to(DEV).requires_grad_(True)
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), pd["V"],
+                               u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), spl)
+    assert torch.equal(s.detach().cpu(), ref.detach())
+    (s * gs.to(DEV)).sum().backward()
+    Fn.check_status()
+    e = relmax(Wxd.grad.cpu().numpy(), Wx.grad.numpy())
+    assert 0.0 < e <= 2e-2, e  # (0 would mean the exact kernels ran)
+    for k in p:
+        assert relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) <= 2e-2, k
+    assert float(torch.diag(pd["V"].grad).abs().max()) == 0.0
 
 
 def test_snn_long_sequence_non_finite_gradient_mask_matches_reference(sp, monkeypatch):
