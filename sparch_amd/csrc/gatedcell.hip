@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_bwd_kernel(LigruArgs a) {
 
 // fragments of ONE matrix for a 16-column product on the 16x16x32 MFMA: column lane & 15 = unit ct*16 + (lane & 15),
 // k = kg*32 + 8*(lane>>4) + j;  transposed == 0: V[unit][k] (q V^T),  1: V[k][unit] (dc_pre V)
-__global__ void gru_vpack16_kernel(int H, int n_ct, int nkg, int transposed, const float* __restrict__ V,
+__global__ void gru_vpack16_kernel(int H, int n_ct, int nkg, int transposed, int rne, const float* __restrict__ V,
                                    u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_ct * nkg * 64;
@@ -859,7 +859,7 @@ __global__ void gru_vpack16_kernel(int H, int n_ct, int nkg, int transposed, con
     for (int j = 0; j < 8; ++j) {
         const int k = kg * 32 + 8 * (lane >> 4) + j;
         const float v = (k < H && unit < H) ? (transposed ? V[(size_t)k * H + unit] : V[(size_t)unit * H + k]) : 0.f;
-        split3(v, pl[0][j], pl[1][j], pl[2][j]);
+        vsplit(v, rne, pl[0][j], pl[1][j], pl[2][j]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -871,7 +871,7 @@ __global__ void gru_vpack16_kernel(int H, int n_ct, int nkg, int transposed, con
 }
 
 // ------------------------------------------------------------------------------ prepack
-__global__ void ligru_vpack_fwd_kernel(int H, int n_ct, int nkg, const float* __restrict__ Vz, const float* __restrict__ Vc,
+__global__ void ligru_vpack_fwd_kernel(int H, int n_ct, int nkg, int rne, const float* __restrict__ Vz, const float* __restrict__ Vc,
                                        u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_ct * nkg * 2 * 64;
@@ -886,7 +886,7 @@ __global__ void ligru_vpack_fwd_kernel(int H, int n_ct, int nkg, const float* __
     for (int j = 0; j < 8; ++j) {
         const int k = kg * 32 + 16 * ks + 8 * (lane >> 5) + j;
         const float v = (k < H && unit < H) ? V[(size_t)unit * H + k] : 0.f;
-        split3(v, pl[0][j], pl[1][j], pl[2][j]);
+        vsplit(v, rne, pl[0][j], pl[1][j], pl[2][j]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -896,7 +896,7 @@ __global__ void ligru_vpack_fwd_kernel(int H, int n_ct, int nkg, const float* __
         vpack[((((size_t)ct * nkg + kg) * 2 + ks) * 3 + p) * 64 + lane] = o;
     }
 }
-__global__ void ligru_vpack_bwd_kernel(int H, int n_ct, int nkg, const float* __restrict__ Vz, const float* __restrict__ Vc,
+__global__ void ligru_vpack_bwd_kernel(int H, int n_ct, int nkg, int rne, const float* __restrict__ Vz, const float* __restrict__ Vc,
                                        u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_ct * nkg * 64;
@@ -911,7 +911,7 @@ __global__ void ligru_vpack_bwd_kernel(int H, int n_ct, int nkg, const float* __
         const int src_unit = kg * UT + (k & 15);           // row of Vz (k < 16) or V (k >= 16)
         const float* V = k < UT ? Vz : Vc;
         const float v = (src_unit < H && unit < H && kg < n_ct) ? V[(size_t)src_unit * H + unit] : 0.f;
-        split3(v, pl[0][j], pl[1][j], pl[2][j]);
+        vsplit(v, rne, pl[0][j], pl[1][j], pl[2][j]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -1055,12 +1055,12 @@ extern "C" int sparch_ligru_vpack(int H, const float* Vz, const float* V, int ba
         const int nkg = 8 * kgw_fwd(H);
         const size_t total = (size_t)n_ct * nkg * 2 * 64;
         hipLaunchKernelGGL(ligru_vpack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, H, n_ct, nkg,
-                           Vz, V, reinterpret_cast<u32x4*>(vpack));
+                           sparch_operand_bf16(), Vz, V, reinterpret_cast<u32x4*>(vpack));
     } else {
         const int nkg = 8 * kgw_bwd(H);
         const size_t total = (size_t)n_ct * nkg * 64;
         hipLaunchKernelGGL(ligru_vpack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, H, n_ct, nkg,
-                           Vz, V, reinterpret_cast<u32x4*>(vpack));
+                           sparch_operand_bf16(), Vz, V, reinterpret_cast<u32x4*>(vpack));
     }
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
@@ -1135,7 +1135,7 @@ extern "C" int sparch_gru_vpack(int H, const float* Vz, const float* Vr, const f
     const int nkg = 8 * (backward ? (kgw > 1 ? kgw / 2 : 1) : kgw);
     const size_t total = (size_t)n_ct * nkg * 64;
     hipLaunchKernelGGL(gru_vpack16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H,
-                       n_ct, nkg, backward ? 1 : 0, V, reinterpret_cast<u32x4*>(vpack_cand));
+                       n_ct, nkg, backward ? 1 : 0, sparch_operand_bf16(), V, reinterpret_cast<u32x4*>(vpack_cand));
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

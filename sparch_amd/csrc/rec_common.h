@@ -101,6 +101,14 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
+// Packing a recurrent matrix.  rne (the bf16 operand mode, sparch_set_operand_precision): plane 0 = the value
+// rounded once to bf16, planes 1 and 2 = 0 — the kernels of that mode read plane 0 only, and any three-plane
+// kernel given such a pack computes products with the same rounded weights.
+__device__ __forceinline__ void vsplit(float v, int rne, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    split3(v, hi, mid, lo);
+    if (rne) { mid = 0; lo = 0; }
+}
+
 // V (or V^T) slice -> registers: per k-group, 2 k16-steps x NP planes of 8 bf16 (4 VGPRs) each (the packed
 // layout always has room for three planes; the bf16 operand mode keeps its one rounded plane in plane 0)
 template <int KGW, int NW, int NP = 3>

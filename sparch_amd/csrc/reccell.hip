@@ -998,12 +998,6 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
 // vpack[ct][kg][ks][p][lane] = 8 bf16 (16 B): plane p (0 hi, 1 mid, 2 lo) of Vm[k][col] (forward) or
 // Vm[col][k] (backward) for k = kg*32 + 16*ks + 8*(lane>>5) + j, j = 0..7, col = ct*32 + (lane&31);
 // Vm = V with a zero diagonal, zero padded.  This is the B-operand fragment of v_mfma_f32_32x32x16_bf16.
-// rne (the bf16 operand mode): plane 0 = V rounded once to bf16, planes 1 and 2 = 0 — the kernels of that mode
-// read plane 0 only, and any three-plane kernel given such a pack computes the same bf16 products.
-__device__ __forceinline__ void vsplit(float v, int rne, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
-    split3(v, hi, mid, lo);
-    if (rne) { mid = 0; lo = 0; }
-}
 __global__ void vpack_kernel(int H, int n_ct, int nkg, int transpose, int rne, const float* __restrict__ V,
                              u32x4* __restrict__ vpack) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -87,6 +87,7 @@ class Experiment:
         self.synthetic_batches = getattr(args, "synthetic_batches", 8)
         self.seq_len = getattr(args, "seq_len", 100)
         self.sync_bn = getattr(args, "sync_bn", False)
+        self.compute_dtype = getattr(args, "compute_dtype", "fp32")
 
         self.rank, self.world, self.local_rank = dp.init_from_env()
         self.is_main = self.rank == 0
@@ -103,6 +104,9 @@ class Experiment:
         self.device = torch.device("cuda", self.local_rank if self.world > 1 else 0)
         torch.cuda.set_device(self.device)
         logging.info(f"\nDevice is set to {self.device}\n")
+        Fn.set_compute_dtype(self.compute_dtype)
+        if self.compute_dtype != "fp32":
+            logging.info("Matrix products run on bf16-rounded operands with fp32 accumulation (--compute_dtype bf16)")
 
         self.init_dataset()
         self.init_model()

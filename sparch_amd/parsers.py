@@ -1,9 +1,9 @@
 """
 Command-line surface of the reference (sparch/parsers/model_config.py:19-65 and
 training_config.py:19-147): the same 7 model flags and 19 training flags, names, types, choices
-and defaults, so `python run_exp.py ...` invocations carry over unchanged.  Three flags are ADDED
-for this build (no dataset files exist offline; multi-GPU is new): --synthetic, --synthetic_batches,
---seq_len.  Booleans accept the distutils.strtobool spellings (distutils is gone in Python >= 3.12).
+and defaults, so `python run_exp.py ...` invocations carry over unchanged.  Flags ADDED for this build
+(no dataset files exist offline; multi-GPU and the bf16 operand mode are new): --synthetic,
+--synthetic_batches, --seq_len, --sync_bn, --compute_dtype.  Booleans accept the distutils.strtobool spellings (distutils is gone in Python >= 3.12).
 """
 import logging
 
@@ -60,6 +60,9 @@ EXTRA_FLAGS = [
     ("seq_len", int, 100, None, "[sparch_amd] time steps of synthetic spiking inputs (loaders bin to 100)."),
     ("sync_bn", strtobool, False, None, "[sparch_amd] data-parallel runs: BatchNorm over the GLOBAL batch "
                                         "(statistics exchanged between ranks) instead of per rank."),
+    ("compute_dtype", str, "fp32", ["fp32", "bf16"],
+     "[sparch_amd] operand precision of the matrix products: fp32 (exact, the reference's arithmetic) or bf16 "
+     "(operands rounded once, fp32 accumulation, states and parameter updates)."),
 ]
 
 

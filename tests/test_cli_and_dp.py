@@ -31,7 +31,8 @@ def test_flag_names_and_defaults_match_reference():
     ns = vars(_parser().parse_args([]))
     for k, v in {**REF_MODEL, **REF_TRAIN}.items():
         assert ns[k] == v, k
-    assert set(ns) - set(REF_MODEL) - set(REF_TRAIN) == {"synthetic", "synthetic_batches", "seq_len", "sync_bn"}
+    assert set(ns) - set(REF_MODEL) - set(REF_TRAIN) == {"synthetic", "synthetic_batches", "seq_len", "sync_bn",
+                                                             "compute_dtype"}
 
 
 def test_flag_parsing_booleans_and_choices():

@@ -1078,11 +1078,24 @@ def test_experiment_cli_synthetic_end_to_end(tmp_path):
     on synthetic SHD-shaped spikes, one epoch, checkpoint written, then reload + test-only run."""
     import run_exp
     folder = str(tmp_path / "exp_lif")
+    # (the reference saves a checkpoint only when the validation accuracy beats the best so far, which starts at
+    # 0: exp.py:263-277.  Seeded, and with enough steps / validation samples of the learnable synthetic task that
+    # this does not hinge on one lucky hit among 12 samples.)
+    torch.manual_seed(20)
     run_exp.main(["--model_type", "LIF", "--nb_layers", "3", "--nb_hiddens", "128", "--dataset_name", "shd",
-                  "--batch_size", "4", "--nb_epochs", "1", "--synthetic", "1", "--synthetic_batches", "3",
+                  "--batch_size", "4", "--nb_epochs", "2", "--synthetic", "1", "--synthetic_batches", "24",
                   "--new_exp_folder", folder, "--use_regularizers", "1"])
     import os
     assert os.path.exists(folder + "/checkpoints/best_model.pth")
+    # the same command line in the bf16 operand mode (--compute_dtype, added by this build)
+    from sparch_amd import functional as Fn
+    try:
+        run_exp.main(["--model_type", "RadLIF", "--nb_layers", "3", "--nb_hiddens", "64", "--dataset_name", "shd",
+                      "--batch_size", "8", "--nb_epochs", "1", "--synthetic", "1", "--synthetic_batches", "3",
+                      "--save_best", "0", "--compute_dtype", "bf16", "--new_exp_folder", str(tmp_path / "exp_bf16")])
+        assert Fn.compute_dtype() == "bf16"
+    finally:
+        Fn.set_compute_dtype("fp32")
     run_exp.main(["--use_pretrained_model", "1", "--only_do_testing", "1", "--load_exp_folder", folder,
                   "--dataset_name", "shd", "--batch_size", "4", "--synthetic", "1", "--synthetic_batches", "2"])
     # raw-audio path (sc): waveform -> HIP fbank -> RadLIF
@@ -1521,14 +1534,18 @@ def test_shd_ssc_loader_batches_binned_on_device():
     assert seen == 11
 
 
-@pytest.mark.parametrize("neuron_type", ["LIF", "RadLIF"])
-def test_training_learns_class_conditional_synthetic_task(sp, neuron_type):
+@pytest.mark.parametrize("neuron_type,compute", [("LIF", "fp32"), ("RadLIF", "fp32"), ("RadLIF", "bf16"),
+                                                 ("adLIF", "bf16")])
+def test_training_learns_class_conditional_synthetic_task(sp, neuron_type, compute, request):
     """End to end: forward + CE on the softmax-sum + backward + one-launch Adam (exp.py:359-377) on the
     synthetic SHD-shaped task whose labels select a band of input channels.  Gradient parity is checked
-    elsewhere; this checks that the pieces train: held-out accuracy far above chance (1/20) after 60 steps."""
+    elsewhere; this checks that the pieces train: held-out accuracy far above chance (1/20) after 60 steps —
+    in the exact fp32 mode and in the bf16 operand mode (same bar)."""
     from sparch_amd.exp import _SyntheticLoader
     from sparch_amd.optim import Adam
 
+    if compute == "bf16":
+        request.getfixturevalue("bf16_mode")
     B, T = 64, 50
     torch.manual_seed(3)
     net = sp.SNN((B, None, 700), [128, 128, 20], neuron_type=neuron_type, dropout=0.1).to(DEV).train()
@@ -1551,6 +1568,136 @@ def test_training_learns_class_conditional_synthetic_task(sp, neuron_type):
             n += B
     assert float(loss.detach()) < 0.7 * first, (first, float(loss.detach()))
     assert hits / n > 0.6, hits / n
+
+
+@pytest.mark.parametrize("kind", ["MLP", "RNN", "LiGRU", "GRU"])
+def test_bf16_operand_mode_baseline_layers_vs_oracle(kind, bf16_mode):
+    """The non-spiking baseline layers in the bf16 operand mode against the fp32 CPU oracle: smooth functions of
+    their weights, so the stated tolerance is the operands' rounding: MLP / RNN / GRU 2e-2 of each tensor's largest
+    entry and 1e-2 relative rms (output and every gradient), LiGRU (ReLU derivative flips, see below) 0.2 / 6e-2,
+    on the persistent recurrent kernels where the layer has them."""
+    from oracle import ann_oracle as ao
+    from sparch_amd import anns
+
+    B, T, C, H = 12, 21, 40, 64
+    torch.manual_seed(29)
+    layer = getattr(anns, kind + "Layer")(C, H, B, dropout=0.0, normalization="batchnorm", use_bias=False)
+    g = torch.Generator().manual_seed(30)
+    x = torch.randn(B, T, C, generator=g)
+    gy = torch.randn(B, T, H, generator=g)
+    p = {"ann.0." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+         for k, v in layer.state_dict().items() if "num_batches" not in k}
+    xr = x.clone().requires_grad_(True)
+    ref = ao.hidden_layer(kind, xr, p, "ann.0", "batchnorm", False, training=True, running=None)
+    (ref * gy).sum().backward()
+    layer = layer.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    (y * gy.to(DEV)).sum().backward()
+    bf16_mode.check_status()
+
+    def relrms(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.sqrt(((a - b) ** 2).sum() / ((b ** 2).sum() + 1e-30)))
+
+    # LiGRU's candidate is a ReLU: a pre-activation within the forward's 2e-3 rounding of zero flips its
+    # derivative (0 / 1), a discrete change no operand precision bounds — measured 0.10 of max-abs / 3.3e-2 rms for
+    # its dx while its output agrees to 2.5e-3; the smooth cells stay at the operands' rounding level
+    tol_max, tol_rms = (0.2, 6e-2) if kind == "LiGRU" else (2e-2, 1e-2)
+    pairs = [("y", y.detach().cpu().numpy(), ref.detach().numpy()), ("dx", xd.grad.cpu().numpy(), xr.grad.numpy())]
+    pairs += [(k, v.grad.cpu().numpy(), p["ann.0." + k].grad.numpy()) for k, v in layer.named_parameters()]
+    assert relmax(pairs[0][1], pairs[0][2]) > 0.0, "the exact kernels ran"
+    for name, got, want in pairs:
+        em, er = relmax(got, want), relrms(got, want)
+        print(f"bf16 operand mode, {kind} {name}: relmax {em:.2e} relrms {er:.2e}")
+        assert em <= tol_max and er <= tol_rms, (name, em, er)
+
+
+@pytest.mark.parametrize("kind", ["adLIF", "RLIF", "RadLIF"])
+def test_bf16_operand_mode_equals_exact_mode_on_rounded_weights(sp, kind, bf16_mode):
+    """Real-valued weights (the reference's initialisation: not bf16-representable).  What the mode does is
+    defined operationally: its forward pass must equal, BIT FOR BIT, the exact fp32 path run on the same network
+    with W and V replaced by their bf16-rounded values (adding the zero mid / lo planes changes no sum) — through
+    the projections, BatchNorm, the recurrent s @ V and the readout.  On that identical spike trajectory the
+    backward pass differs only by the bf16 rounding of dWx in its matrix products: every parameter gradient
+    within 2e-2 of its max-abs.  (`a` is kept >= 0 so that the subthreshold (u, w) map contracts: with a -> -1 the
+    reference's own gradients grow like 1.4^T and amplify any rounding; see the T = 1000 fixture.)"""
+    Fn = bf16_mode
+    B, T, C, sizes = 24, 30, 96, [128, 128, 20]
+    g = torch.Generator().manual_seed(78)
+    x = (torch.rand(B, T, C, generator=g) < 0.15).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+    torch.manual_seed(5)
+    net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.0, normalization="batchnorm").to(DEV).train()
+    with torch.no_grad():
+        for lay in net.snn:
+            if hasattr(lay, "a"):
+                lay.a.uniform_(0.0, 1.0)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def run(mode, rounded):
+        Fn.set_compute_dtype(mode)
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        if rounded:
+            with torch.no_grad():
+                for k, v in net.named_parameters():
+                    if k.endswith("W.weight") or k.endswith("V.weight"):
+                        v.copy_(v.to(torch.bfloat16).float())
+        torch.manual_seed(6)
+        out, rates = net(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        Fn.check_status()
+        return out.detach().clone(), rates.detach().clone(), {k: v.grad.clone() for k, v in net.named_parameters()}
+
+    out_b, rates_b, g_b = run("bf16", rounded=False)
+    out_f, rates_f, g_f = run("fp32", rounded=True)
+    out_x, rates_x, _ = run("fp32", rounded=False)
+    Fn.set_compute_dtype("bf16")
+    assert float(rates_b.sum()) > 0
+    assert torch.equal(rates_b, rates_f) and torch.equal(out_b, out_f), "forward of the bf16 mode != exact path on rounded weights"
+    assert not torch.equal(out_b, out_x), "the weights were bf16-exact: the test would prove nothing"
+    worst = 0.0
+    for k in g_b:
+        e = relmax(g_b[k].cpu().numpy(), g_f[k].cpu().numpy())
+        worst = max(worst, e)
+        assert e <= 2e-2, (k, e)
+    print(f"{kind}: worst gradient relmax, bf16 mode vs exact path on rounded weights: {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind", ["adLIF", "RadLIF"])
+def test_bf16_operand_mode_real_valued_network_statistics(sp, kind, bf16_mode):
+    """A network with the reference's real-valued initial weights in both modes on the same draws: rounding the
+    weights moves membrane potentials by ~2^-9 relative, a few potentials cross the threshold the other way and
+    the spike trains then differ, so (as for the real-valued recurrent fixtures) the comparison with the fp32 path
+    is statistical — stated bars: mean |firing-rate difference| <= 0.01, loss within 5 % (measured 5e-4, 0.6 %).
+    Gradients are NOT compared here: at the reference's initialisation (a in [-1, 1]) they are dominated by the
+    expanding subthreshold modes and change sign under a handful of spike flips in either mode; the rigorous
+    gradient check of the mode is test_bf16_operand_mode_equals_exact_mode_on_rounded_weights."""
+    Fn = bf16_mode
+    B, T, C, sizes = 32, 60, 120, [128, 128, 20]
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(B, T, C, generator=g) < 0.1).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        Fn.set_compute_dtype(mode)
+        torch.manual_seed(5)
+        net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.0, normalization="batchnorm").to(DEV).train()
+        torch.manual_seed(6)
+        out, rates = net(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        Fn.check_status()
+        res[mode] = (rates.detach().cpu(), float(loss.detach()), {k: v.grad.cpu() for k, v in net.named_parameters()})
+    Fn.set_compute_dtype("bf16")
+    (r0, l0, g0), (r1, l1, g1) = res["fp32"], res["bf16"]
+    assert float(r0.sum()) > 0 and not torch.equal(r0, r1), "the two modes ran the same kernels"
+    assert float((r0 - r1).abs().mean()) <= 0.01
+    assert abs(l0 - l1) <= 0.05 * abs(l0)
+    for k in g1:
+        assert bool(torch.isfinite(g1[k]).all()), k
 
 
 @pytest.mark.parametrize("kind,bidir,norm", [("LiGRU", True, "batchnorm"), ("GRU", True, "layernorm"),
