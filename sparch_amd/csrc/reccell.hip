@@ -304,6 +304,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         }
 
         // ---- pointwise membrane update for this thread's 4 neurons
+        // (Hoisting the rec-independent part of this update in front of the poll was measured: 0.75 -> 0.81 ms
+        // per launch — its use of x_t there waits, in order, for the previous step's bulk stores.)
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         f32x4 uo, wo;
         unsigned nib = 0;
@@ -522,6 +524,30 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+        // Everything of the reverse step that does not depend on the recurrent product — the dropout factor's
+        // hash, the incoming gradient, alpha * du_{t+1}, the adaptation terms — is computed BEFORE the reduction
+        // barrier, behind the first tile loads' issue (the pointwise waves would only wait there): the chain
+        // behind the barrier is then `+ rec`, the box-car gate, two adds and a multiply.  Same operations in the
+        // same order as the reference's autograd replay: bit-identical results.
+        const int tt = d ? (T - 1 - t) : t;
+        const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
+        const int pt = tid & 255;
+        float pre_ds[4], pre_aldu[4], pre_padw[4];
+        auto pre_pointwise = [&]() __attribute__((always_inline)) {
+            const f32x4 al = pconst[0][pt], pa = pconst[2][pt], pb = pconst[3][pt], gr = pconst[4][pt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
+                const float gs = (gv[e] + gr[e]) * k;
+                pre_aldu[e] = al[e] * du_n[e];
+                float ds = gs - pre_aldu[e];
+                pre_padw[e] = ADAPT ? pa[e] * dw_n[e] : 0.f;
+                if (ADAPT) ds = ds + pb[e] * dw_n[e];
+                pre_ds[e] = ds;
+                asm volatile("" : "+v"(pre_ds[e]), "+v"(pre_aldu[e]), "+v"(pre_padw[e]));  // not sunk behind the barrier
+            }
+        };
+        if (!(t + 1 < T && !EXT) && pw) pre_pointwise();
 
         if (t + 1 < T && !EXT) {
             // ---- the dWx_{t+1} tiles of this wave's producers: load, re-load what has not landed yet
@@ -545,6 +571,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
             for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW, NP>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             PROF_STAMP(0);  // first tile load issue
+            if (pw) pre_pointwise();
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -605,9 +632,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
         }
 
-        // ---- pointwise reverse step
-        const int tt = d ? (T - 1 - t) : t;
-        const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
+        // ---- pointwise reverse step (its rec-independent part: pre_pointwise above)
         float sp[4];
         if (t > 0) {
 #pragma unroll
@@ -619,18 +644,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
         f32x4 dwx, spv;
         float du_new[4], dw_new[4];
-        const int pt = tid & 255;
-        const f32x4 al = pconst[0][pt], be = pconst[1][pt], pa = pconst[2][pt], pb = pconst[3][pt], gr = pconst[4][pt];
+        const f32x4 al = pconst[0][pt], be = pconst[1][pt];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
-            const float gs = (gv[e] + gr[e]) * k;
-            float ds = gs - al[e] * du_n[e];
-            if (ADAPT) ds = ds + pb[e] * dw_n[e];
-            ds = ds + rec[e];
+            const float ds = pre_ds[e] + rec[e];
             const float xs = u_t[e] - a.theta;
-            float du = boxcar_gate(ds, xs) + al[e] * du_n[e];                 // snns.py:33-35
-            if (ADAPT) du = du + pa[e] * dw_n[e];
+            float du = boxcar_gate(ds, xs) + pre_aldu[e];                     // snns.py:33-35
+            if (ADAPT) du = du + pre_padw[e];
             dwx[e] = valid ? (1.0f - al[e]) * du : 0.0f;
             du_new[e] = du;
             dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
