@@ -269,7 +269,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 // section free of branches lets the scheduler interleave LUT reads with the MFMA chain
                 const unsigned wbits = (wave + NW * kk < a.n_ct) ? (unsigned)gran[kk] : 0u;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[kk][ks] = lut[(wbits >> (16 * ks + 8 * hh)) & 0xFFu];
+                for (int ks = 0; ks < 2; ++ks) {
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_LUT)  // timing ablation (wrong results): no LDS table read
+                    const unsigned by = (wbits >> (16 * ks + 8 * hh)) & 0xFFu;
+                    af[kk][ks] = u32x4{by, by ^ 0x3F80u, by, by};
+#else
+                    af[kk][ks] = lut[(wbits >> (16 * ks + 8 * hh)) & 0xFFu];
+#endif
+                }
             }
             f32x16 acc;
 #pragma unroll
@@ -279,7 +286,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int p = NP - 1; p >= 0; --p) acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
+                    for (int p = NP - 1; p >= 0; --p) {
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_MFMA)  // timing ablation (wrong results): operands kept alive, no MFMA
+                        asm volatile("" ::"v"(af[kk][ks]), "v"(vb[kk][ks][p]));
+#else
+                        acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
+#endif
+                    }
             float* rd = red[t & 1][wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
