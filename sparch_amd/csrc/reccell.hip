@@ -202,6 +202,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     f32x4 pend_s = {0.f, 0.f, 0.f, 0.f}, pend_u = pend_s, pend_w = pend_s;
     int pend_t = -1;
     auto flush_pending = [&]() {
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_BULK)  // timing ablation (no outputs): the step's HBM stores dropped
+        pend_t = -1;
+        return;
+#endif
         if (pend_t >= 0 && valid) {
             const int ptt = d ? (T - 1 - pend_t) : pend_t;
             const size_t o_s = ((size_t)b * T + ptt) * HO + (size_t)d * H + colc;
@@ -305,6 +309,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         lds_barrier();
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
+        if (t > 0 && !EXT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rec[e] = red[t & 1][0][r * RED_LD + cq * 4 + e];
+        }
+#else
         if (t > 0 && !EXT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -315,6 +325,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 rec[e] = sum;
             }
         }
+#endif
 
         // ---- pointwise membrane update for this thread's 4 neurons
         // (Hoisting the rec-independent part of this update in front of the poll was measured: 0.75 -> 0.81 ms
