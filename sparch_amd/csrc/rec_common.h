@@ -35,6 +35,9 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #ifndef REC_ST_AUX
 #define REC_ST_AUX 16 /* sc1 */
 #endif
+#ifndef REC_XSTORE
+#define REC_XSTORE 0  /* forward: bulk stores issued by the waves without pointwise state (measured: slower, see reccell.hip) */
+#endif
 #ifndef REC_AHEAD
 #define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
 #endif

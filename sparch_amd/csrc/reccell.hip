@@ -201,25 +201,49 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     // would put their HBM latency in front of the sweep.  Issued behind it they retire under the MFMA phase.
     f32x4 pend_s = {0.f, 0.f, 0.f, 0.f}, pend_u = pend_s, pend_w = pend_s;
     int pend_t = -1;
+    // XSTORE (build option REC_XSTORE=1, 8-wave kernels; OFF: measured 0.76 -> 0.81 ms per launch, bit-identical
+    // results): the stores issued by the four waves that hold NO pointwise state.  A step's (s, u, w) go through
+    // an LDS staging buffer; after the next step's reduction barrier the upper waves read them and issue the
+    // global stores while the pointwise waves run their update — the stores then sit in THOSE waves' memory
+    // queues, not in front of the pointwise waves' poll (`vmcnt` is in order and counts stores).  But the upper
+    // waves poll too, with LESS lead over their stores (a pointwise phase instead of a whole step), and the
+    // matrix phase waits for its slowest wave: the timing ablation's 0.75 k cycles (no stores at all) cannot be
+    // had by moving the stores between waves of the same workgroup.
+    constexpr bool XSTORE = REC_XSTORE && NW == 8 && !EXT;
+    __shared__ __attribute__((aligned(16))) f32x4 stage[XSTORE ? 2 : 1][3][XSTORE ? 256 : 1];
+    const bool valid_hi = !pw && bp < a.Bp && col < H;  // an upper-wave thread, same (row, columns) as tid - 256
+    auto store_step = [&](int st_t, const f32x4& vs, const f32x4& vu, const f32x4& vw) {
+        const int ptt = d ? (T - 1 - st_t) : st_t;
+        const size_t o_s = ((size_t)b * T + ptt) * HO + (size_t)d * H + colc;
+        st4(a.s_out + o_s, vs);
+        if (a.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
+            u32x2 h;
+            h.x = (vs[0] != 0.f ? 0x3F80u : 0u) | (vs[1] != 0.f ? 0x3F800000u : 0u);
+            h.y = (vs[2] != 0.f ? 0x3F80u : 0u) | (vs[3] != 0.f ? 0x3F800000u : 0u);
+            *reinterpret_cast<u32x2*>(a.s16_out + o_s) = h;
+        }
+        st4_saved<true>(a.u_save, ((size_t)bp * T + st_t) * H + col, vu, a.save16, a.theta);
+        if (ADAPT) st4_saved<false>(a.w_save, ((size_t)bp * T + st_t) * H + col, vw, a.save16, a.theta);
+    };
     auto flush_pending = [&]() {
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_BULK)  // timing ablation (no outputs): the step's HBM stores dropped
         pend_t = -1;
         return;
 #endif
-        if (pend_t >= 0 && valid) {
-            const int ptt = d ? (T - 1 - pend_t) : pend_t;
-            const size_t o_s = ((size_t)b * T + ptt) * HO + (size_t)d * H + colc;
-            st4(a.s_out + o_s, pend_s);
-            if (a.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
-                u32x2 h;
-                h.x = (pend_s[0] != 0.f ? 0x3F80u : 0u) | (pend_s[1] != 0.f ? 0x3F800000u : 0u);
-                h.y = (pend_s[2] != 0.f ? 0x3F80u : 0u) | (pend_s[3] != 0.f ? 0x3F800000u : 0u);
-                *reinterpret_cast<u32x2*>(a.s16_out + o_s) = h;
-            }
-            st4_saved<true>(a.u_save, ((size_t)bp * T + pend_t) * H + col, pend_u, a.save16, a.theta);
-            if (ADAPT) st4_saved<false>(a.w_save, ((size_t)bp * T + pend_t) * H + col, pend_w, a.save16, a.theta);
-        }
+        if (!XSTORE && pend_t >= 0 && valid) store_step(pend_t, pend_s, pend_u, pend_w);
         pend_t = -1;
+    };
+    auto flush_staged = [&](int st_t) {  // upper waves: the staged step st_t -> HBM
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_BULK)
+        return;
+#endif
+        if (valid_hi) {
+            const int q = tid & 255;
+            const f32x4 vs = stage[st_t & 1][0][q], vu = stage[st_t & 1][1][q];
+            f32x4 vw = vs;
+            if (ADAPT) vw = stage[st_t & 1][2][q];
+            store_step(st_t, vs, vu, vw);
+        }
     };
     PROF_DECL
 
@@ -309,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         lds_barrier();
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[t & 1]) break;
+        if (XSTORE && t > a.t_begin) flush_staged(t - 1);  // (the barrier above ordered the staging writes)
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
         if (t > 0 && !EXT) {
 #pragma unroll
@@ -380,12 +405,23 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 so[e] = s[e] * k;
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
-            pend_s = so; pend_u = uo; pend_w = wo;
+            if (XSTORE) {
+                stage[t & 1][0][tid] = so; stage[t & 1][1][tid] = uo;
+                if (ADAPT) stage[t & 1][2][tid] = wo;
+            } else {
+                pend_s = so; pend_u = uo; pend_w = wo;
+            }
         }
         pend_t = t;
         PROF_STAMP(4);  // dropout
     }
-    flush_pending();
+    if (XSTORE) {  // the last step of the launch (skipped after an abort: the step is discarded anyway)
+        const bool aborted = (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]) != 0;
+        __syncthreads();
+        if (!aborted && a.t_end > a.t_begin) flush_staged(a.t_end - 1);
+    } else {
+        flush_pending();
+    }
     PROF_FLUSH(0)
 
     // ---- spike counts (post-dropout) -> one integer atomic per (direction, column) per workgroup
