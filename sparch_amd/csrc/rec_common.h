@@ -38,6 +38,9 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #ifndef REC_XSTORE
 #define REC_XSTORE 0  /* forward: bulk stores issued by the waves without pointwise state (measured: slower, see reccell.hip) */
 #endif
+#ifndef REC_BWD_XSTORE
+#define REC_BWD_XSTORE 1  /* backward: bulk stores issued one step later by the waves without pointwise state */
+#endif
 #ifndef REC_AHEAD
 #define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
 #endif

@@ -470,6 +470,16 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #endif
     __shared__ int abort_flag[2];
     __shared__ int xcd_local_flag;
+    // BXS (8-wave kernels): the step's bulk HBM stores (dWx for the GEMMs, the bf16 plane of s_{t-1}) are issued
+    // by the four waves that hold NO pointwise state, one step later: the pointwise waves stage the 24 bytes per
+    // thread in LDS after the publish barrier, the upper waves pick them up behind the NEXT step's reduction
+    // barrier — where they would otherwise idle through the pointwise phase — and issue the stores there, ~2.4 k
+    // cycles ahead of their own next tile loads.  On the pointwise waves the stores sat ~0.8 k cycles in front of
+    // the next step's tile loads, and `vmcnt` (in order, counts stores) made the first k-group wait for their
+    // acknowledgement: timing ablation without the stores 1.29 -> 1.16 ms per launch.
+    constexpr bool BXS = REC_BWD_XSTORE && NW == 8 && !EXT;
+    __shared__ __attribute__((aligned(16))) f32x4 stage_dwx[BXS ? 256 : 1];
+    __shared__ __attribute__((aligned(8))) u32x2 stage_sp[BXS ? 256 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -483,6 +493,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
     const bool valid = pw && bp < a.Bp && col < H;
+    const bool valid_hi = !pw && bp < a.Bp && col < H;  // upper-wave thread: same (row, columns) as tid - 256
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
@@ -678,6 +689,11 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
         if (*(volatile int*)&abort_flag[par]) break;
+        if (BXS && valid_hi && t + 1 < a.t_end) {  // the previous step's staged outputs -> HBM (upper waves)
+            const int t1 = t + 1, tt1 = d ? (T - 1 - t1) : t1;
+            st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
+            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt1) * H + col) = stage_sp[tid & 255];
+        }
         if (t + 1 < T && EXT) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
@@ -771,12 +787,20 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #endif
         PROF_STAMP(4);  // publish barrier
         // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
+#if defined(SPARCH_REC_PROF) && defined(BA_NO_BULK)  // timing ablation (no outputs): the step's HBM stores dropped
+        if (false) {
+#else
         if (valid) {
-            st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
+#endif
             u32x2 h;  // s_{t-1} (binary for t >= 1, zero row at t = 0) as a bf16 plane for the dV product
             h.x = (spv[0] != 0.f ? 0x3F80u : 0u) | (spv[1] != 0.f ? 0x3F800000u : 0u);
             h.y = (spv[2] != 0.f ? 0x3F80u : 0u) | (spv[3] != 0.f ? 0x3F800000u : 0u);
-            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt) * H + col) = h;
+            if (BXS) {
+                stage_dwx[tid] = dwx; stage_sp[tid] = h;
+            } else {
+                st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
+                *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt) * H + col) = h;
+            }
         }
         if (pw) {
             f32x4 v_al = PACC(0, pt), v_be, v_a, v_b;
@@ -813,6 +837,17 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         PROF_STAMP(5);  // fp32 stores + partial sums
     }
     PROF_FLUSH(1)
+    if (BXS) {  // the launch's last step is still staged (after an abort the step is discarded anyway)
+        const bool aborted = (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]) != 0;
+        __syncthreads();
+#if !(defined(SPARCH_REC_PROF) && defined(BA_NO_BULK))
+        if (!aborted && valid_hi && a.t_end > a.t_begin) {
+            const int t1 = a.t_begin, tt1 = d ? (T - 1 - t1) : t1;
+            st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
+            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt1) * H + col) = stage_sp[tid & 255];
+        }
+#endif
+    }
     if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
