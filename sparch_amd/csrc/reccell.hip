@@ -594,7 +594,16 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx, xrv = xr_nx;
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
+        // The next step's inputs (g, u, w, raw projection: HBM loads) are prefetched IN FRONT of this step's tile
+        // loads.  (Build option REC_BWD_LATE_PREFETCH=1 issues them behind the last tile load instead, so that no
+        // HBM round trip sits between the pointwise waves and their first k-group, `vmcnt` being in order —
+        // measured 1.20 -> 1.26 ms per launch: the tiles have not landed at that point anyway, and the late loads
+        // then arrive into the pointwise phase.)
+#if REC_BWD_LATE_PREFETCH
+        if (!(t + 1 < T && !EXT) && pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#else
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#endif
         // Everything of the reverse step that does not depend on the recurrent product — the dropout factor's
         // hash, the incoming gradient, alpha * du_{t+1}, the adaptation terms — is computed BEFORE the reduction
         // barrier, behind the first tile loads' issue (the pointwise waves would only wait there): the chain
@@ -676,6 +685,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     }
                 }
             }
+#if REC_BWD_LATE_PREFETCH
+            if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#endif
             float* rd = red[wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
