@@ -55,7 +55,16 @@ constexpr unsigned SENTINEL = 0x7FA5A5A5u;
 
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+#ifndef REC_NT_STORES
+#define REC_NT_STORES 0  /* bulk output stores of the recurrent kernels as non-temporal stores (measured: no change) */
+#endif
+__device__ __forceinline__ void st4(float* p, f32x4 v) {
+#if REC_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 // saved states (u, w) as fp32 or bf16 (element index i)
 __device__ __forceinline__ f32x4 ld4_saved(const float* base, size_t i, bool s16) {
     if (!s16) return ld4(base + i);
