@@ -447,11 +447,15 @@ def test_bf16_saved_states_keep_every_discrete_decision(kind, Bp, T, H, monkeypa
     print(f"bf16 saved states, {kind}: worst neuron-parameter gradient deviation {worst:.2e} of max-abs")
 
 
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
 @pytest.mark.parametrize("kind", ["RLIF", "RadLIF"])
-def test_recurrent_step_path_equals_persistent_kernels(kind, monkeypatch):
+def test_recurrent_step_path_equals_persistent_kernels(kind, compute, monkeypatch, request):
     """The step path (one launch per time step, recurrent product between the steps on the exact split
     GEMMs: what hidden sizes above 1024 use) against the persistent kernels at a size both handle, dyadic V:
-    identical spikes, dWx and gradients to fp32 rounding (the two differ only in summation order)."""
+    identical spikes, dWx and gradients to fp32 rounding (the two differ only in summation order) — also in
+    the bf16 operand mode, where both paths multiply the same rounded dWx and V."""
+    if compute == "bf16":
+        request.getfixturevalue("bf16_mode")
     case = _dyadic_cell_case(kind, 40, 21, 132, 5)
     s_a, dwx_a, g_a = _run_cell(kind, *case)
     monkeypatch.setenv("SPARCH_REC_STEP_PATH", "1")
