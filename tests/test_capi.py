@@ -54,3 +54,22 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.sparch_readout_fwd(2, 3, 257, 1, None, None, 1, 1, 1, None, None) == -1  # C > 256
     assert lib.sparch_cell_fwd(2, 1, 1, 1, 4, 16, None, None, 16, None, None, None, 16, None, 16,
                                1.0, 0.0, 0, 16, None, None, None, 0, None, None) == -1  # kind RLIF on non-recurrent entry
+
+
+def test_operand_precision_switch_is_host_state():
+    """sparch_set_operand_precision (the bf16 operand mode, BASELINE configs[4]): fp32-exact by default, unknown
+    modes rejected, and the Python wrapper maps the names (no GPU involved: the switch only selects which kernel
+    instantiation the next launch takes)."""
+    from sparch_amd import functional as Fn
+    lib = _capi.lib
+    assert lib.sparch_get_operand_precision() == 0 and Fn.compute_dtype() == "fp32"
+    assert lib.sparch_set_operand_precision(7) == -1 and lib.sparch_get_operand_precision() == 0
+    try:
+        assert Fn.set_compute_dtype("bfloat16") == "fp32" and Fn.compute_dtype() == "bf16"
+        assert lib.sparch_get_operand_precision() == 1
+        assert Fn.set_compute_dtype("fp32") == "bf16"
+        import pytest
+        with pytest.raises(ValueError):
+            Fn.set_compute_dtype("fp8")
+    finally:
+        lib.sparch_set_operand_precision(0)
