@@ -646,7 +646,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // With the producers' data always ready (consuming step t+2's tiles, a timing experiment) the step is
             // 9.7 k cycles against 10.2 k: the phase is throughput-, not hand-off-latency-bound — L2 port
             // 3.7 k, and MFMA (3.1 k) + split VALU (2.8 k) add up on the SIMD instead of overlapping.
-            constexpr int AHEAD = KGW < REC_AHEAD ? KGW : REC_AHEAD;
+            // (bf16 operand mode, NP = 1: a third of the bytes — all k-groups are issued at once; one group ahead
+            // made that mode's tile phase four sequential L2 round trips, 3.2 k cycles with 16 MFMAs per SIMD)
+            constexpr int AHEAD = NP == 1 ? KGW : (KGW < REC_AHEAD ? KGW : REC_AHEAD);
             u32x4 raw[KGW][2][NP];  // [k-group][k16-step][plane]: MFMA A fragments as they come off the wire
 #pragma unroll
             for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW, NP>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
