@@ -322,19 +322,25 @@ template <int MODE, bool FAST, bool BIG = false> struct Shape {
     // covered by the other's MFMAs) in one workgroup per CU; general kernel: 4 waves, 2 workgroups per CU.
     static constexpr int WM = FAST ? (MODE == 1 ? 4 : 2) : 2;   // waves along M
     static constexpr int WN = FAST ? (MODE == 1 ? 2 : 4) : 2;   // waves along N
-    static constexpr int WI = FAST ? (MODE == 0 ? 4 : (MODE == 1 ? (BIG ? 2 : 1) : 2)) : 2;  // 32-row MFMA tiles per wave
-    static constexpr int WJ = FAST ? (MODE == 1 ? 4 : (MODE == 0 && BIG ? 2 : 1)) : 2;
+    static constexpr int WI = FAST ? (MODE == 0 ? 4 : (MODE == 1 ? (BIG ? 2 : 1) : (BIG ? 4 : 2))) : 2;  // 32-row MFMA tiles per wave
+    static constexpr int WJ = FAST ? (MODE == 1 ? 4 : (BIG ? 2 : 1)) : 2;
     static constexpr int BM = 32 * WI * WM, BN = 32 * WJ * WN;
     static constexpr int NT = 64 * WM * WN;
     // workgroups per CU the register / LDS budget is set for
     static constexpr int OCC = FAST ? 1 : (MODE == 2 ? 2 : 3);
 };
 
+// 256 x 256 workgroup tiles: the TN spike kernels of the exact mode, and EVERY pipelined kernel of the bf16 operand
+// mode (NP = 1: one plane per operand, so the images of a 256 x 256 tile fit two LDS stages, and a 32-deep K tile
+// of the smaller shapes holds only 4-8 MFMAs per wave between two barriers)
+template <bool A_KM, bool B_KM, int MODE, bool FAST, int NP>
+constexpr bool big_tile() { return FAST && ((A_KM && B_KM && MODE != 2) || NP == 1); }
+
 extern __shared__ __attribute__((aligned(16))) unsigned short dyn_lds[];
 
 template <bool A_KM, bool B_KM, int MODE, bool FAST, int NP = 3>
 constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of both operand tiles)
-    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
+    using S = Shape<MODE, FAST, big_tile<A_KM, B_KM, MODE, FAST, NP>()>;
     return (MODE == 0 ? 1 : NP) * plane_elems<A_KM, S::BM>() + (MODE == 1 ? 1 : NP) * plane_elems<B_KM, S::BN>();
 }
 
@@ -353,7 +359,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     static_assert(!S16 || MODE != 2, "a bf16 plane is a spike operand");
     static_assert(!BPRE || (FAST && MODE != 1), "pre-split B: pipelined kernel, B is the dense operand");
     static_assert(NP == 3 || (NP == 1 && !BPRE), "dense operands: three exact planes or one rounded plane");
-    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
+    constexpr bool BIGT = big_tile<A_KM, B_KM, MODE, FAST, NP>();
+    using S = Shape<MODE, FAST, BIGT>;
     constexpr bool SPIKE_A = MODE == 0;
     constexpr bool SPIKE_B = MODE == 1;
     constexpr int WI = S::WI, WJ = S::WJ, WN = S::WN, BM = S::BM, BN = S::BN, NT = S::NT;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     const int lin_end = (xcd + 1) * (total >> 3) + min(xcd + 1, total & 7);
     // (the general kernels and the 256 x 256 TN kernels — long K ranges, one item per workgroup — have no
     // registers to spare for a loop: theirs is a single trip at compile time)
-    constexpr bool WALKS = FAST && !(A_KM && B_KM && MODE != 2);
+    constexpr bool WALKS = FAST && !BIGT;
     int lin = xcd * (total >> 3) + min(xcd, total & 7) + idx;
     if (lin >= lin_end) return;
     do {
@@ -412,7 +419,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     // FAST: two register sets, tiles in flight two K tiles ahead of the MFMAs (a load issued in phase t is
     // converted in phase t + 2; one phase of a 256 x 128 tile is ~0.8 us, less than a loaded HBM round trip)
     // (not the 256 x 256 TN kernels: their phase is twice as long and they have no registers to spare)
-    constexpr bool AHEAD2 = FAST && !(A_KM && B_KM && MODE != 2);
+    constexpr bool AHEAD2 = FAST && !BIGT;
     f32x4 ra[NPA], rb[NPB];
     [[maybe_unused]] f32x4 ra2[AHEAD2 ? NPA : 1], rb2[AHEAD2 ? NPB : 1];
 
@@ -734,8 +741,15 @@ int target_wgs(int occ) {
     return occ * cus;
 }
 template <int MODE>
-int choose_splits(int M, int N, int K) {
-    using S = Shape<MODE, true, MODE != 2>;  // TN products only
+int choose_splits(int M, int N, int K) {  // TN products only
+    if (sparch_operand_bf16()) {  // every pipelined kernel of that mode works on 256 x 256 tiles
+        using SB = Shape<MODE, true, true>;
+        const int tiles_b = cdiv(M, SB::BM) * cdiv(N, SB::BN);
+        int sb = target_wgs(1) / tiles_b;
+        if (sb > cdiv(K, BK) / 8) sb = cdiv(K, BK) / 8;
+        return sb < 1 ? 1 : sb;
+    }
+    using S = Shape<MODE, true, MODE != 2>;
     const int tiles = cdiv(M, S::BM) * cdiv(N, S::BN);
     const int kt = cdiv(K, BK);
     int s = target_wgs(1) / tiles;  // the pipelined kernel runs one workgroup per CU
@@ -743,9 +757,9 @@ int choose_splits(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16, int NP = 3>
 bool fast_ok(const SArgs& g) {
-    using S = Shape<MODE, true, A_KM && B_KM && MODE != 2>;
+    using S = Shape<MODE, true, big_tile<A_KM, B_KM, MODE, true, NP>()>;
     constexpr int BM = S::BM, BN = S::BN;
     constexpr int QA = (S16 && MODE == 0) ? 8 : 4, QB = (S16 && MODE == 1) ? 8 : 4;  // elements per 16 bytes
     // the shifted-edge-tile kernel needs whole tiles to exist, 16-byte rows, and (for the BatchNorm
@@ -757,14 +771,15 @@ bool fast_ok(const SArgs& g) {
 
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
-    using S = Shape<MODE, FAST, FAST && A_KM && B_KM && MODE != 2>;
+    constexpr bool BIGT = big_tile<A_KM, B_KM, MODE, FAST, NP>();
+    using S = Shape<MODE, FAST, BIGT>;
     const int work = cdiv(g.M, S::BM) * cdiv(g.N, S::BN) * splits;
     g.n_splits = splits;
     // pipelined kernels (one workgroup per CU): more work items than CUs -> a persistent grid of one workgroup
     // per CU walking them (SPARCH_GEMM_PERSISTENT=0: one workgroup per item)
     static const bool persistent = [] { const char* e = getenv("SPARCH_GEMM_PERSISTENT"); return !e || atoi(e) != 0; }();
     const int cus = target_wgs(1);
-    const int wgs = (FAST && !(A_KM && B_KM && MODE != 2) && persistent && work > cus) ? cus : work;
+    const int wgs = (FAST && !BIGT && persistent && work > cus) ? cus : work;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST, NP>() * sizeof(unsigned short);
     auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE, NP>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -778,7 +793,7 @@ int launch_variant(SArgs& g, int splits, hipStream_t st) {
 template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16 = false>
 int launch(SArgs& g, int splits, hipStream_t st) {
     if (sparch_operand_bf16()) {  // bf16 operand mode: the same kernels with ONE rounded plane per dense operand
-        if (fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
+        if (fast_ok<A_KM, B_KM, MODE, EPI, S16, 1>(g))
             return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, false, 1>(g, splits, st);
         return launch_variant<A_KM, B_KM, MODE, EPI, false, S16, false, 1>(g, splits, st);
     }
