@@ -6,7 +6,7 @@ There is no CPU fallback: importing this package without the built library fails
 """
 from . import _capi  # noqa: F401  (fails loudly when libsparch_hip.so is missing)
 from . import optim  # noqa: F401
-from .functional import bin_events, check_status, fbank  # noqa: F401
+from .functional import bin_events, check_status, compute_dtype, fbank, set_compute_dtype  # noqa: F401
 from .snns import (SNN, LIFLayer, RLIFLayer, RadLIFLayer, ReadoutLayer,  # noqa: F401
                    SpikeFunctionBoxcar, adLIFLayer)
 
