@@ -1478,10 +1478,15 @@ def test_full_size_cfg_audio_frontend_to_radlif(sp):
 
 
 @pytest.mark.gpu
-def test_full_size_cfg_bidirectional_long_sequence(sp):
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_full_size_cfg_bidirectional_long_sequence(sp, compute, request, monkeypatch):
     """BASELINE.json configs[4] at full size on one GPU: bidirectional RadLIF [1024,1024,1024,35], B=256,
-    T=1000 (512 virtual rows: two groups of row tiles per launch sequence); fp32 (>= the config's bf16)."""
+    T=1000 (512 virtual rows: two groups of row tiles per launch sequence); in fp32 (>= the config's bf16) and
+    as the configuration names it: the bf16 operand mode with bf16 saved states."""
     Fn = _Fn()
+    if compute == "bf16":
+        request.getfixturevalue("bf16_mode")
+        monkeypatch.setattr(Fn, "SAVE_BF16", True)
     B, T, C = 256, 1000, 700
     torch.manual_seed(1234)
     net = sp.SNN((B, None, C), [1024, 1024, 1024, 35], neuron_type="RadLIF", dropout=0.0, bidirectional=True).to(DEV)
@@ -1831,8 +1836,8 @@ def test_gemm_shape_sweep_pipelined_and_general_paths():
 
 # ------------------------------------------------------------------ the training step as one HIP graph
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["adLIF", "RadLIF"])
-def test_graphed_train_step_matches_eager_steps(sp, kind):
+@pytest.mark.parametrize("kind,compute", [("adLIF", "fp32"), ("RadLIF", "fp32"), ("RadLIF", "bf16")])
+def test_graphed_train_step_matches_eager_steps(sp, kind, compute, request):
     """sparch_amd.graph.GraphedTrainStep (zero_grad -> forward -> CE -> backward -> Adam as ONE captured HIP
     graph; dropout seeds, Adam's per-step factors and the random initial states come from device memory)
     against the same steps run eagerly: same initial parameters, same CPU generator seed (so the same initial
@@ -1842,6 +1847,8 @@ def test_graphed_train_step_matches_eager_steps(sp, kind):
     from sparch_amd.graph import GraphedTrainStep
     from sparch_amd.optim import Adam
 
+    if compute == "bf16":  # the operand mode is read when a launch is enqueued: captured with the graph
+        request.getfixturevalue("bf16_mode")
     B, T, C, sizes = 16, 25, 40, [64, 64, 20]
     g = torch.Generator().manual_seed(3)
     x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
