@@ -473,7 +473,18 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         timer.stop(tok)
     else:
         if H % 4 != 0:
-            raise ValueError("sparch_amd: recurrent layers need hidden_size % 4 == 0")
+            # The recurrent kernels own 4 columns per thread.  Any other width (the reference takes any nb_hiddens,
+            # snns.py:608-661) runs zero-padded to the next multiple of 4: a padded neuron has no input, no
+            # recurrent weights and u0 = 0, so it never spikes and feeds nothing; outputs are sliced back.
+            H4 = (H + 3) // 4 * 4
+            padh = lambda t_: None if t_ is None else torch.nn.functional.pad(t_, (0, H4 - H))  # noqa: E731
+            pp = {k_: (torch.nn.functional.pad(v, (0, H4 - H, 0, H4 - H)) if k_ == "V" else padh(v)) for k_, v in p.items()}
+            s_p, count_p, saved_p, s16_p = cell_forward(kind, padh(Wx), padh(scale), padh(shift), pp, padh(u0), padh(w0),
+                                                        padh(s0), B=B, dirs=dirs, theta=theta, p_drop=p_drop, seed=seed,
+                                                        steps_per_launch=steps_per_launch)
+            cut = lambda t_: t_.view(B, T, dirs, H4)[..., :H].reshape(B, T, dirs * H).contiguous()  # noqa: E731
+            return (cut(s_p), count_p.view(dirs, H4)[:, :H].reshape(-1).contiguous(), saved_p,
+                    None if s16_p is None else cut(s16_p))
         V = p["V"]
         if rec_step_path(H):
             # One launch per time step, the recurrent product s_{t-1} @ V between the steps on the exact
@@ -525,6 +536,16 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
     u_save, w_save = saved[0], saved[1]
+    if recurrent and u_save.shape[-1] != H:  # forward ran zero-padded to a multiple of 4 columns (see cell_forward)
+        H4 = u_save.shape[-1]
+        padh = lambda t_: None if t_ is None else torch.nn.functional.pad(t_, (0, H4 - H))  # noqa: E731
+        pp = {k_: (torch.nn.functional.pad(v, (0, H4 - H, 0, H4 - H)) if k_ == "V" else padh(v)) for k_, v in p.items()}
+        g_p = padh(g_out.reshape(B, T, dirs, H)).reshape(B, T, dirs * H4)
+        gr_p = None if g_rate is None else padh(g_rate.reshape(dirs, H)).reshape(dirs * H4)
+        dWx_p, gp = cell_backward(kind, g_p, gr_p, pp, padh(u0), padh(w0), padh(s0), saved, B=B, dirs=dirs, T=T, H=H4,
+                                  theta=theta, p_drop=p_drop, seed=seed, steps_per_launch=steps_per_launch, bn=None)
+        grads = {k_: (v[:H, :H].contiguous() if k_ == "V" else v[:H].contiguous()) for k_, v in gp.items()}
+        return dWx_p[..., :H].contiguous(), grads
     vpack_fwd_made = saved[2] if len(saved) > 2 else None  # backward fragments of V packed by cell_forward
     save16 = u_save.dtype == torch.bfloat16
     dWx = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)

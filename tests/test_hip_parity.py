@@ -610,6 +610,72 @@ def test_recurrent_backward_vs_oracle_autograd(kind):
         assert float(torch.diag(pd["V"].grad).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind,H", [("RLIF", 66), ("RadLIF", 130), ("RadLIF", 7), ("RLIF", 1030)])
+def test_recurrent_cell_any_hidden_size(kind, H):
+    """The reference takes any nb_hiddens (snns.py:608-661); the recurrent kernels own 4 columns per thread, so a
+    width that is not a multiple of 4 runs zero-padded (functional.cell_forward): dyadic V, spikes bit-equal to the
+    oracle, every gradient (oracle autograd) to 2e-4 of its max-abs, shapes as the caller's."""
+    Wx, p, u0, w0, s0, gs = _dyadic_cell_case(kind, 9, 14, H, 40 + H)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    Wx.requires_grad_(True)
+    ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+    (ref * gs).sum().backward()
+    s, dwx, g = _run_cell(kind, Wx.detach(), {k: v.detach() for k, v in p.items()}, u0, w0, s0, gs)
+    assert tuple(s.shape) == tuple(ref.shape) and ref.sum() > 0
+    assert torch.equal(s, ref.detach())
+    assert relmax(dwx.numpy(), Wx.grad.numpy()) <= 2e-4
+    for k in p:
+        assert tuple(g[k].shape) == tuple(p[k].shape)
+        assert relmax(g[k].numpy(), p[k].grad.numpy()) <= 2e-4, k
+    assert float(torch.diag(g["V"]).abs().max()) == 0.0
+
+
+def test_snn_with_hidden_sizes_not_multiples_of_four(sp):
+    """Whole networks at widths the kernels do not take natively (130 recurrent units, 30 LIF units, 20 classes):
+    the HIP path against the CPU oracle on a dyadic network — per-neuron spike counts equal, loss and every
+    parameter gradient to fp32 rounding; bidirectional, so that the per-direction slicing of the padded outputs is
+    exercised."""
+    B, T, C = 6, 20, 44
+    for kind, sizes, bidir in (("RadLIF", [130, 66, 20], True), ("LIF", [30, 30, 20], False)):
+        torch.manual_seed(11)
+        net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.0, normalization="none", bidirectional=bidir)
+        with torch.no_grad():
+            for lay in net.snn:
+                lay.W.weight.copy_(torch.round(lay.W.weight * 4 * 64) / 64)
+                if hasattr(lay, "V"):
+                    lay.V.weight.copy_(torch.round(lay.V.weight * 64) / 64)
+        params = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(5)
+        x = (torch.rand(B, T, C, generator=g) < 0.3).float()
+        y = torch.randint(0, sizes[-1], (B,), generator=g)
+        torch.manual_seed(7)
+        init = orc.draw_init_states(B, sizes, kind, bidirectional=bidir)
+        init = [{k: torch.floor(v * 16) / 16 for k, v in st.items()} for st in init]
+        order = iter([st[k] for st in init for k in ("u0", "w0", "s0") if k in st])
+        from sparch_amd import snns as snn_mod
+        old = snn_mod._rand_to
+        snn_mod._rand_to = lambda rows, cols, device: next(order).to(device)
+        try:
+            net = net.to(DEV).train()
+            out, rates = net(x.to(DEV))
+            loss = torch.nn.functional.cross_entropy(out, y.to(DEV))
+            loss.backward()
+            _Fn().check_status()
+        finally:
+            snn_mod._rand_to = old
+        po = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in params.items()}
+        out_o, rates_o = orc.snn_forward(x, po, neuron_type=kind, num_layers=3, init_states=init,
+                                         normalization="none", training=True, stats={}, bidirectional=bidir)
+        loss_o = torch.nn.functional.cross_entropy(out_o, y)
+        loss_o.backward()
+        n = B * T
+        assert float(rates_o.sum()) > 0
+        assert torch.equal(torch.round(rates.detach().cpu() * n).long(), torch.round(rates_o.detach() * n).long()), kind
+        assert abs(float(loss.detach()) - float(loss_o.detach())) <= 1e-5 * max(1.0, abs(float(loss_o.detach())))
+        for k, v in net.named_parameters():
+            assert relmax(v.grad.cpu().numpy(), po[k].grad.numpy()) <= 2e-4, (kind, k)
+
+
 @pytest.mark.parametrize("spl", [1, None])
 @pytest.mark.parametrize("kind,Bp,T,H", [("RLIF", 48, 60, 128), ("RadLIF", 96, 80, 256), ("RadLIF", 33, 40, 1024)])
 def test_recurrent_one_step_ahead_vs_oracle_trajectory(kind, Bp, T, H, spl):
