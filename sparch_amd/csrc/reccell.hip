@@ -1461,7 +1461,10 @@ extern "C" size_t sparch_rec_chan_bytes(int Bp, int T, int H) {
     if (Bp <= 0 || T <= 0 || H <= 0) return 0;
     // forward: T x row tiles x column tiles x 32 granules of 8 B; backward: fp32 tile ring
     const size_t f = fwd_chan_bytes(Bp, T, H), b = bwd_pring_bytes(Bp, H);
-    return (f > b ? f : b) + xcd_tab_bytes(Bp, H);
+    // rounded up to 16 bytes: the agreement table is 4 bytes per workgroup, and a caller that sizes its buffer in
+    // 8-byte words (round 2: `nbytes // 8` in the Python host) must not come out 4 bytes short of the table's
+    // last word when the number of workgroups is odd
+    return ((f > b ? f : b) + xcd_tab_bytes(Bp, H) + 15) & ~(size_t)15;
 }
 
 extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx,

@@ -514,7 +514,7 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         # that its 16 output tiles become a full grid (38 -> ~15 us at B' = 256, H = 1024)
         rec0 = _gemm_small(s0, vmask, nn=True)
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-        chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
         tok = timer.start(f"rec_cell_fwd[{kind}]")
         check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
                                       ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
@@ -587,7 +587,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                 vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
                 check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
             tok = timer.start(f"rec_cell_bwd[{kind}]")
             check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
@@ -1014,7 +1014,7 @@ class RNNLayerFn(torch.autograd.Function):
             vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # y V^T, dense
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_fwd[RNN]")
             check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
                                          ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state),
@@ -1051,7 +1051,7 @@ class RNNLayerFn(torch.autograd.Function):
             vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # dpre V, dense
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_bwd[RNN]")
             check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(g_y), ptr(y_state), ptr(vpack),
                                          cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
@@ -1144,7 +1144,7 @@ class GatedLayerFn(torch.autograd.Function):
             check(lib.sparch_gru_vpack(H, ptr(P["z"]["V"]), ptr(P["r"]["V"]), ptr(P["c"]["V"]), 0, ptr(vg), ptr(vc),
                                        _stream()), "sparch_gru_vpack")
             nbytes = lib.sparch_gru_chan_bytes(Bp, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("gru_fwd")
             check(lib.sparch_gru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
                                      ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]),
@@ -1158,7 +1158,7 @@ class GatedLayerFn(torch.autograd.Function):
             vp = torch.empty(lib.sparch_ligru_vpack_bytes(H, 0) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_ligru_vpack(H, ptr(P["z"]["V"]), ptr(P["c"]["V"]), 0, ptr(vp), _stream()), "sparch_ligru_vpack")
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ligru_fwd")
             check(lib.sparch_ligru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
                                        ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]), ptr(vp),
@@ -1214,7 +1214,7 @@ class GatedLayerFn(torch.autograd.Function):
             check(lib.sparch_gru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["r"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vg), ptr(vc),
                                        _stream()), "sparch_gru_vpack")
             nbytes = lib.sparch_gru_chan_bytes(Bp, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)
             tok = timer.start("gru_bwd")
             check(lib.sparch_gru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
@@ -1226,7 +1226,7 @@ class GatedLayerFn(torch.autograd.Function):
             vpb = torch.empty(lib.sparch_ligru_vpack_bytes(H, 1) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_ligru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vpb), _stream()), "sparch_ligru_vpack")
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
-            chan = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+            chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)
             tok = timer.start("ligru_bwd")
             check(lib.sparch_ligru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(c_save), ptr(vpb),

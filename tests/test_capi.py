@@ -44,6 +44,9 @@ def test_host_only_entry_points():
     assert lib.sparch_vpack_bytes(2048) == 0                 # V slice would not fit the register file: step path
     # forward granules (T x row tiles x column tiles x 32 rows x 8 B) + one agreement word per workgroup
     assert lib.sparch_rec_chan_bytes(256, 250, 1024) == 250 * 8 * 32 * 32 * 8 + 8 * 32 * 4
+    # one workgroup: ring of 4 x 6 KiB plane tiles + ONE 4-byte table word, rounded up to 16 bytes (a caller sizing
+    # its buffer in 8-byte words must not lose the table word)
+    assert lib.sparch_rec_chan_bytes(9, 14, 8) == 4 * 6144 + 16
     assert lib.sparch_gemm_tn_workspace_bytes(1024, 1024, 64000) == 16 * 1024 * 1024 * 4
     assert lib.sparch_bn_bwd_workspace_bytes(64000, 1024) == 2 * 250 * 1024 * 4
 

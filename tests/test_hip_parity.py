@@ -623,6 +623,8 @@ def test_recurrent_cell_any_hidden_size(kind, H):
     s, dwx, g = _run_cell(kind, Wx.detach(), {k: v.detach() for k, v in p.items()}, u0, w0, s0, gs)
     assert tuple(s.shape) == tuple(ref.shape) and ref.sum() > 0
     assert torch.equal(s, ref.detach())
+    assert bool(torch.isfinite(Wx.grad).all()), "oracle gradient not finite"
+    assert bool(torch.isfinite(dwx).all()), ("HIP dWx not finite", torch.isnan(dwx).nonzero()[:8].tolist())
     assert relmax(dwx.numpy(), Wx.grad.numpy()) <= 2e-4
     for k in p:
         assert tuple(g[k].shape) == tuple(p[k].shape)
