@@ -678,6 +678,94 @@ def test_snn_with_hidden_sizes_not_multiples_of_four(sp):
             assert relmax(v.grad.cpu().numpy(), po[k].grad.numpy()) <= 2e-4, (kind, k)
 
 
+def test_cell_kernels_shape_fuzz_vs_oracle():
+    """All four cells over a grid of awkward shapes — 1 / 2 / 31 / 33 / 65 rows, 1 / 2 / 5 steps, 1 / 3 / 4 / 5 / 31 /
+    33 / 63 / 96 / 100 units, whole-sequence and one-step launches — one after the other in one process (so that what
+    a launch leaves behind meets the next shape's buffers): dyadic V, spikes bit-equal to the oracle, dWx and every
+    parameter gradient to 2e-4 of max-abs."""
+    import itertools
+    Fn = _Fn()
+    bad = []
+    for kind in ("RadLIF", "RLIF", "adLIF", "LIF"):
+        rec = kind in ("RLIF", "RadLIF")
+        adapt = kind in ("adLIF", "RadLIF")
+        for Bp, T, H in itertools.product((1, 2, 31, 33, 65), (1, 2, 5), (1, 3, 4, 5, 31, 33, 63, 96, 100)):
+            if (Bp + T + H) % 2 and not rec:   # (half of the non-recurrent grid: it has no hand-off machinery)
+                continue
+            for spl in ((None, 1) if rec else (None,)):
+                Wx, p, u0, w0, s0, gs = _dyadic_cell_case("RadLIF" if adapt else "RLIF", Bp, T, H, 7 * H + Bp + T)
+                if not rec:
+                    p.pop("V")
+                p = {k: v.requires_grad_(True) for k, v in p.items()}
+                Wx.requires_grad_(True)
+                ref = orc.spiking_cell(kind, Wx, p, u0, w0 if adapt else None, s0)
+                (ref * gs).sum().backward()
+                pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in p.items()}
+                Wxd = Wx.detach().to(DEV).requires_grad_(True)
+                s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"),
+                                           pd.get("V"), u0.to(DEV), w0.to(DEV) if adapt else None, s0.to(DEV), spl)
+                (s * gs.to(DEV)).sum().backward()
+                e = relmax(Wxd.grad.cpu().numpy(), Wx.grad.numpy())
+                eg = max(relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) for k in p)
+                if not torch.equal(s.detach().cpu(), ref.detach()) or not e <= 2e-4 or not eg <= 2e-4:
+                    bad.append((kind, Bp, T, H, spl, e, eg))
+    Fn.check_status()
+    assert not bad, bad[:10]
+
+
+def test_snn_random_configurations_vs_oracle(sp):
+    """Forty whole networks drawn at random — LIF / adLIF / RLIF / RadLIF, 1-33 rows, 1-19 steps, 1-70 input channels,
+    hidden widths 1-100 (most not multiples of 4), 1-130 classes, with and without bias, bidirectional, readout —
+    on dyadic weights against the CPU oracle: per-neuron spike counts equal, outputs to 1e-4, every parameter
+    gradient to 5e-4 of its max-abs."""
+    from sparch_amd import snns as snn_mod
+    rng = np.random.default_rng(5)
+    bad = []
+    for it in range(40):
+        kind = ["LIF", "adLIF", "RLIF", "RadLIF"][it % 4]
+        B, T, C = int(rng.choice([1, 2, 5, 17, 33])), int(rng.choice([1, 2, 7, 19])), int(rng.choice([1, 3, 20, 33, 70]))
+        nl = int(rng.choice([2, 3]))
+        sizes = [int(rng.choice([1, 3, 5, 12, 30, 33, 64, 100])) for _ in range(nl - 1)] + [int(rng.choice([1, 3, 20, 35, 130]))]
+        bidir, bias, readout = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(4) > 0)
+        torch.manual_seed(100 + it)
+        net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.0, normalization="none", bidirectional=bidir,
+                     use_bias=bias, use_readout_layer=readout)
+        with torch.no_grad():
+            for lay in net.snn:
+                lay.W.weight.copy_(torch.round(lay.W.weight * 4 * 64) / 64)
+                if lay.W.bias is not None:
+                    lay.W.bias.copy_(torch.round(lay.W.bias * 64) / 64)
+                if hasattr(lay, "V"):
+                    lay.V.weight.copy_(torch.round(lay.V.weight * 64) / 64)
+        params = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(it)
+        x = (torch.rand(B, T, C, generator=g) < 0.4).float()
+        torch.manual_seed(7 + it)
+        init = orc.draw_init_states(B, sizes, kind, bidirectional=bidir, use_readout_layer=readout)
+        init = [{k: torch.floor(v * 16) / 16 for k, v in st.items()} for st in init]
+        order = iter([st[k] for st in init for k in ("u0", "w0", "s0") if k in st])
+        old = snn_mod._rand_to
+        snn_mod._rand_to = lambda rows, cols, device, order=order: next(order).to(device)
+        try:
+            net = net.to(DEV).train()
+            out, rates = net(x.to(DEV))
+            gout = torch.randn(out.shape, generator=g)
+            (out * gout.to(DEV)).sum().backward()
+            _Fn().check_status()
+        finally:
+            snn_mod._rand_to = old
+        po = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in params.items()}
+        out_o, rates_o = orc.snn_forward(x, po, neuron_type=kind, num_layers=nl, init_states=init, normalization="none",
+                                         training=True, stats={}, bidirectional=bidir, use_readout_layer=readout)
+        (out_o * gout).sum().backward()
+        same = torch.equal(torch.round(rates.detach().cpu() * B * T).long(), torch.round(rates_o.detach() * B * T).long())
+        eo = relmax(out.detach().cpu().numpy(), out_o.detach().numpy())
+        eg = max(relmax(v.grad.cpu().numpy(), po[k].grad.numpy()) for k, v in net.named_parameters())
+        if not same or not eo <= 1e-4 or not eg <= 5e-4:
+            bad.append((kind, (B, T, C), sizes, bidir, bias, readout, same, eo, eg))
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("spl", [1, None])
 @pytest.mark.parametrize("kind,Bp,T,H", [("RLIF", 48, 60, 128), ("RadLIF", 96, 80, 256), ("RadLIF", 33, 40, 1024)])
 def test_recurrent_one_step_ahead_vs_oracle_trajectory(kind, Bp, T, H, spl):
