@@ -678,6 +678,32 @@ def test_snn_with_hidden_sizes_not_multiples_of_four(sp):
             assert relmax(v.grad.cpu().numpy(), po[k].grad.numpy()) <= 2e-4, (kind, k)
 
 
+@pytest.mark.parametrize("kind,Bp,T,H,spl", [("RadLIF", 288, 4, 1024, None), ("RLIF", 520, 3, 1024, None),
+                                             ("RadLIF", 300, 5, 512, None), ("RadLIF", 288, 4, 1024, 2),
+                                             ("RLIF", 260, 3, 992, None), ("RadLIF", 70, 6, 1000, 3),
+                                             ("RLIF", 1030, 2, 96, None), ("RadLIF", 97, 7, 96, 3)])
+def test_recurrent_cell_many_row_tiles_and_chunked_launches(kind, Bp, T, H, spl):
+    """More row tiles than one persistent launch holds (9 and 17 row tiles of 32 column tiles on 256 CUs: two and
+    three launch groups), an odd number of workgroups, partial last tiles, chunked launches: dyadic V, spikes
+    bit-equal to the oracle, dWx and every parameter gradient to 2e-4 of max-abs."""
+    Wx, p, u0, w0, s0, gs = _dyadic_cell_case(kind, Bp, T, H, 3 * H + Bp)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    Wx.requires_grad_(True)
+    ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+    (ref * gs).sum().backward()
+    Fn = _Fn()
+    pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in p.items()}
+    Wxd = Wx.detach().to(DEV).requires_grad_(True)
+    s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), pd["V"],
+                               u0.to(DEV), None if w0 is None else w0.to(DEV), s0.to(DEV), spl)
+    (s * gs.to(DEV)).sum().backward()
+    Fn.check_status()
+    assert ref.sum() > 0 and torch.equal(s.detach().cpu(), ref.detach())
+    assert relmax(Wxd.grad.cpu().numpy(), Wx.grad.numpy()) <= 2e-4
+    for k in p:
+        assert relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) <= 2e-4, k
+
+
 def test_cell_kernels_shape_fuzz_vs_oracle():
     """All four cells over a grid of awkward shapes — 1 / 2 / 31 / 33 / 65 rows, 1 / 2 / 5 steps, 1 / 3 / 4 / 5 / 31 /
     33 / 63 / 96 / 100 units, whole-sequence and one-step launches — one after the other in one process (so that what
