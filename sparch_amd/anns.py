@@ -13,6 +13,7 @@ library's GEMMs and the gate arithmetic in `sparch_gate_step` (csrc/annstep.hip)
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import functional as Fn
 from .snns import _SpikingLayer  # dropout seed helper
@@ -136,6 +137,42 @@ class _HiddenANNLayer(_ANNLayer):
         return {"normalization": self.normalization, "training": self.training, "dirs": dirs, "p_drop": p_drop,
                 "seed": self._dropout_seed(x.device) if p_drop > 0 else 0}
 
+    # ---- widths that are not multiples of 4 (the kernels own 4 columns per thread; the reference takes any
+    # nb_hiddens, anns.py:149-595): the layer runs zero-padded to the next multiple of 4.  A padded unit has zero
+    # input weights and zero recurrent weights in both directions, so it feeds nothing; its outputs are sliced away
+    # and, the padding being torch.nn.functional.pad, autograd slices the gradients back by itself.  LayerNorm
+    # normalises over the width and is therefore not paddable.
+    def _pad_width(self):
+        H = self.hidden_size
+        H4 = (H + 3) // 4 * 4
+        if H4 != H and self.normalization == "layernorm":
+            raise ValueError("sparch_amd: non-spiking baseline layers with layernorm need hidden_size % 4 == 0")
+        return H4 - H
+
+    @staticmethod
+    def _padded(t, extra, square=False):
+        if t is None or extra == 0:
+            return t
+        pad = (0, extra, 0, extra) if square else ((0, 0) * (t.ndim - 1) + (0, extra))
+        return F.pad(t, pad)
+
+    @staticmethod
+    def _padded_rows(w, extra):
+        return w if extra == 0 else F.pad(w, (0, 0, 0, extra))
+
+    def _finish(self, y, extra, dirs, padded_running):
+        """Slice the padded output per direction; copy the padded running statistics back."""
+        for (rm, rv), (rm_p, rv_p) in padded_running:
+            if rm is not None and rm_p is not rm:
+                with torch.no_grad():
+                    rm.copy_(rm_p[:rm.numel()])
+                    rv.copy_(rv_p[:rv.numel()])
+        if extra == 0:
+            return y
+        B, T = y.shape[0], y.shape[1]
+        H = self.hidden_size
+        return y.view(B, T, dirs, H + extra)[..., :H].reshape(B, T, dirs * H)
+
 
 class MLPLayer(_HiddenANNLayer):
     """anns.py:149-227: y = dropout(sigmoid(norm(W x)))."""
@@ -146,8 +183,12 @@ class MLPLayer(_HiddenANNLayer):
         if self.batch_size != x.shape[0]:
             self.batch_size = x.shape[0]
         nw, nb, rm, rv = self._norm_args()
-        cfg = dict(self._cfg(x, 1), act="sigmoid", running_mean=rm, running_var=rv)
-        return Fn.MLPLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)
+        extra = self._pad_width()
+        rm_p, rv_p = self._padded(rm, extra), self._padded(rv, extra)
+        cfg = dict(self._cfg(x, 1), act="sigmoid", running_mean=rm_p, running_var=rv_p)
+        y = Fn.MLPLayerFn.apply(cfg, x, self._padded_rows(self.W.weight, extra), self._padded(self.W.bias, extra),
+                                self._padded(nw, extra), self._padded(nb, extra))
+        return self._finish(y, extra, 1, [((rm, rv), (rm_p, rv_p))])
 
 
 class _RecurrentANNLayer(_HiddenANNLayer):
@@ -165,13 +206,17 @@ class _RecurrentANNLayer(_HiddenANNLayer):
         dirs = self._rows(x)
         mats = {"": "c", "z": "z", "r": "r"}
         params, running = [], {}
+        extra, back = self._pad_width(), []
         for g in self.GATES:
             W, V = getattr(self, "W" + g), getattr(self, "V" + g)
             nw, nb, rm, rv = self._norm_args("norm" + g)
-            params += [W.weight, W.bias, nw, nb, V.weight]
-            running[mats[g]] = (rm, rv)
+            rm_p, rv_p = self._padded(rm, extra), self._padded(rv, extra)
+            params += [self._padded_rows(W.weight, extra), self._padded(W.bias, extra), self._padded(nw, extra),
+                       self._padded(nb, extra), self._padded(V.weight, extra, square=True)]
+            running[mats[g]] = (rm_p, rv_p)
+            back.append(((rm, rv), (rm_p, rv_p)))
         cfg = dict(self._cfg(x, dirs), kind=self.KIND, running=running)
-        return Fn.GatedLayerFn.apply(cfg, x, *params)
+        return self._finish(Fn.GatedLayerFn.apply(cfg, x, *params), extra, dirs, back)
 
 
 class RNNLayer(_RecurrentANNLayer):
@@ -186,8 +231,13 @@ class RNNLayer(_RecurrentANNLayer):
         Fn._require_device(x, "input")
         dirs = self._rows(x)
         nw, nb, rm, rv = self._norm_args()
-        cfg = dict(self._cfg(x, dirs), act="sigmoid", running_mean=rm, running_var=rv)
-        return Fn.RNNLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb, self.V.weight)
+        extra = self._pad_width()
+        rm_p, rv_p = self._padded(rm, extra), self._padded(rv, extra)
+        cfg = dict(self._cfg(x, dirs), act="sigmoid", running_mean=rm_p, running_var=rv_p)
+        y = Fn.RNNLayerFn.apply(cfg, x, self._padded_rows(self.W.weight, extra), self._padded(self.W.bias, extra),
+                                self._padded(nw, extra), self._padded(nb, extra),
+                                self._padded(self.V.weight, extra, square=True))
+        return self._finish(y, extra, dirs, [((rm, rv), (rm_p, rv_p))])
 
 
 class LiGRULayer(_RecurrentANNLayer):
@@ -229,7 +279,12 @@ class ReadoutLayerANN(_ANNLayer):
         Fn._require_device(x, "input")
         nw, nb, rm, rv = self._norm_args()
         cfg = {"normalization": self.normalization, "training": self.training, "running_mean": rm, "running_var": rv}
-        return Fn.ReadoutANNFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb)
+        W = self.W.weight
+        extra = (-self.input_size) % 4
+        if extra:  # the softmax-sum kernels take 4 features per thread: pad with features whose softmax weight is 0
+            x = F.pad(x, (0, extra), value=-1e30)
+            W = F.pad(W, (0, extra))
+        return Fn.ReadoutANNFn.apply(cfg, x, W, self.W.bias, nw, nb)
 
 
 _HIDDEN_CLASSES = {"MLP": MLPLayer, "RNN": RNNLayer, "LiGRU": LiGRULayer, "GRU": GRULayer}
