@@ -162,6 +162,19 @@ int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda, const floa
 int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, int zero_diag, int accumulate,
                         const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream);
+/* The same with the flagged operand's bf16 plane made by the check itself: sparch_plane_bf16_exact writes
+ * plane[m][k] = upper 16 bits of x[m][k] (the exact value whenever the flag stays 1; rows of ldp >= K elements,
+ * ldp % 8 == 0, columns K.. zero) in the pass that computes the flag, and the _auto16_ GEMMs read that plane
+ * (2 bytes per element through the spike-plane kernels) when *flag == 1, the fp32 operand through the six-term
+ * kernels otherwise.  One pass over the network input per step instead of three. */
+int sparch_plane_bf16_exact(int M, int K, const float* x, int ldx, uint16_t* plane, int ldp, uint32_t* flag,
+                            void* stream);
+int sparch_gemm_auto16_nt(int M, int N, int K, const float* A, int lda, const uint16_t* A16, int lda16,
+                          const float* B, int ldb, float* C, int ldc, const float* bias, float* colstat_ws,
+                          const uint32_t* a_exact_flag, void* stream);
+int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          const uint16_t* B16, int ldb16, float* C, int ldc, int zero_diag, int accumulate,
+                          const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream);
 int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          int spike_side, float scale, float* C, int ldc, int zero_diag,
                          int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -57,6 +57,10 @@ PROTOTYPES = {
     "sparch_gemm_auto_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),
     "sparch_gemm_auto_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P,
                                     c_size_t, P]),
+    "sparch_plane_bf16_exact": (c_int, [c_int, c_int, P, c_int, P, c_int, P, P]),
+    "sparch_gemm_auto16_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),
+    "sparch_gemm_auto16_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int,
+                                      P, P, c_size_t, P]),
     "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
                                    P, P, P, P, P, P]),
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

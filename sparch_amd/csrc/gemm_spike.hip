@@ -1157,6 +1157,105 @@ extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda,
     return SPARCH_OK;
 }
 
+// ---- the same check that ALSO writes the bf16 plane of x (upper halves; the exact values when the flag stays 1):
+// one pass over the network input per step instead of the flag pass plus two fp32 reads by the first layer's
+// GEMMs, which then read 2 bytes per element through the spike-plane kernels.  Plane rows are ldp >= K elements
+// (a multiple of 8: 16-byte loadable), columns K .. ldp-1 zero.
+__global__ void plane_flag_kernel(int M, int K, int ldx, int ldp, const float* __restrict__ x,
+                                  unsigned short* __restrict__ plane, unsigned* __restrict__ flag) {
+    const int q = ldp / 4;  // 4-element pieces per plane row
+    const size_t total = (size_t)M * q;
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / q;
+        const int k = (int)(i - m * q) * 4;
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (k + e < K) ? __float_as_uint(x[m * ldx + k + e]) : 0u;
+        bad |= (w[0] | w[1] | w[2] | w[3]) & 0xFFFFu;
+        u32x2 o;
+        o.x = (w[0] >> 16) | (w[1] & 0xFFFF0000u);
+        o.y = (w[2] >> 16) | (w[3] & 0xFFFF0000u);
+        *reinterpret_cast<u32x2*>(plane + m * ldp + k) = o;
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0u);
+}
+
+extern "C" int sparch_plane_bf16_exact(int M, int K, const float* x, int ldx, uint16_t* plane, int ldp,
+                                       uint32_t* flag, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || K <= 0 || !x || !plane || !flag || ldx < K || ldp < K || ldp % 8 != 0) return SPARCH_EINVAL;
+    if (!aligned16(plane)) return SPARCH_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, st, flag, 1u);
+    SPARCH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(plane_flag_kernel, dim3(2048), dim3(256), 0, st, M, K, ldx, ldp, x, plane, flag);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+// The device-gated products with the flagged operand's plane at hand: flag == 1 -> the spike-plane kernel reads the
+// plane (2 bytes per element, no conversion); flag == 0 -> the six-term kernel on the fp32 operand, as before.
+extern "C" int sparch_gemm_auto16_nt(int M, int N, int K, const float* A, int lda, const uint16_t* A16, int lda16,
+                                     const float* B, int ldb, float* C, int ldc, const float* bias,
+                                     float* colstat_ws, const uint32_t* a_exact_flag, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !A16 || !B || !C || lda < K || lda16 < K || ldb < K || ldc < N ||
+        !a_exact_flag)
+        return SPARCH_EINVAL;
+    SArgs g{};
+    g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
+    g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    g.gate = a_exact_flag; g.e_exact = 1;
+    hipStream_t st = (hipStream_t)stream;
+    g.A = reinterpret_cast<const float*>(A16); g.lda = lda16;
+    g.a_vec = aligned16(A16) && (lda16 % 8 == 0);
+    g.gate_want = 1;
+    int rc = colstat_ws ? launch<false, false, 0, EPI_BIAS | EPI_STATS, true>(g, 1, st)
+                        : launch<false, false, 0, EPI_BIAS, true>(g, 1, st);
+    if (rc != SPARCH_OK) return rc;
+    g.A = A; g.lda = lda; g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.gate_want = 0;
+    if (colstat_ws) return launch<false, false, 2, EPI_BIAS | EPI_STATS>(g, 1, st);
+    return launch<false, false, 2, EPI_BIAS>(g, 1, st);
+}
+
+extern "C" int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                     const uint16_t* B16, int ldb16, float* C, int ldc, int zero_diag,
+                                     int accumulate, const uint32_t* b_exact_flag, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !B16 || !C || lda < M || ldb < N || ldb16 < N || ldc < N ||
+        !b_exact_flag)
+        return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = choose_splits<1>(M, N, K);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
+    SArgs g{};
+    g.A = A; g.M = M; g.N = N; g.K = K; g.lda = lda; g.scale = 1.0f;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    g.gate = b_exact_flag; g.e_exact = 1;
+    g.B = reinterpret_cast<const float*>(B16); g.ldb = ldb16;
+    g.b_vec = aligned16(B16) && (ldb16 % 8 == 0);
+    g.gate_want = 1;
+    int rc = launch<true, true, 1, EPI_NONE, true>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    g.B = B; g.ldb = ldb; g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    g.gate_want = 0;
+    rc = launch<true, true, 2, EPI_NONE>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
 #if defined(SPARCH_REC_PROF) && !defined(GA_NO_STAMPS)
 extern "C" int sparch_gemm_prof_read(unsigned long long* host_out, int reset) {
     static unsigned long long zero[8 + 8 * 2];

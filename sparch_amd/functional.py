@@ -226,6 +226,22 @@ def flag_bf16_exact(x):
     return flag
 
 
+USE_INPUT_PLANE = os.environ.get("SPARCH_INPUT_PLANE", "1") != "0"
+
+
+def plane_bf16_exact(x2):
+    """(plane, flag) of a (M, K) fp32 network input: the bf16 plane of x (rows padded to a multiple of 8 elements,
+    zeros behind column K) and the device flag "every element is bf16-exact", made in ONE pass — the first
+    layer's GEMMs then read the plane (2 bytes per element) when the flag is 1 and x itself otherwise."""
+    M, K = x2.shape
+    ldp = (K + 7) // 8 * 8
+    plane = torch.empty(M, ldp, dtype=torch.bfloat16, device=x2.device)
+    flag = torch.empty(4, dtype=torch.int32, device=x2.device)
+    check(lib.sparch_plane_bf16_exact(M, K, ptr(x2), x2.stride(0), ptr(plane), ldp, ptr(flag), _stream()),
+          "sparch_plane_bf16_exact")
+    return plane, flag
+
+
 def split_planes(W):
     """The three exact bf16 planes of a weight matrix, (3, *W.shape) bf16 (W = p0 + p1 + p2 exactly, the
     truncation split the GEMM kernels otherwise redo in every workgroup that stages a tile of W); None where
@@ -237,7 +253,8 @@ def split_planes(W):
     return planes
 
 
-def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None, a16=None, b_planes=None):
+def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None, a16=None, b_planes=None,
+            a_plane=None):
     """A (M,K) @ B (N,K)^T (+bias) -> (M,N); optional BatchNorm column-stat partials.
     spike_scale = c: A's entries are 0 or c (a spike train) -> exact bf16-split MFMA path;
     a16: the same spikes as a (M,K) bf16 0/1 plane (read instead of A);
@@ -261,6 +278,11 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None,
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
                                        ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
+    elif a_exact_flag is not None and a_plane is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
+        tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")  # a_plane: plane_bf16_exact(A)[0], read when the flag is 1
+        check(lib.sparch_gemm_auto16_nt(M, N, K, ptr(A), A.stride(0), ptr(a_plane), a_plane.stride(0), ptr(B),
+                                        B.stride(0), ptr(C), N, ptr(bias), ptr(ws), ptr(a_exact_flag), _stream()),
+              "sparch_gemm_auto16_nt")
     elif a_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
         tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_auto_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
@@ -290,7 +312,8 @@ def gemm_nn(A, B, b_planes=None):
     return C
 
 
-def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b_exact_flag=None, spike16=False):
+def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b_exact_flag=None, spike16=False,
+            b_plane=None):
     """A (K,M)^T @ B (K,N) -> (M,N); contraction over the long leading axis.
     spike_side 0/1: A / B is a spike tensor (entries 0 or spike_scale) -> exact bf16-split MFMA path;
     spike16: that operand is given as a bf16 0/1 plane (torch.bfloat16).
@@ -315,6 +338,14 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b
         check(lib.sparch_gemm_spike_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
                                        float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
                                        ptr(ws), nbytes, _stream()), "sparch_gemm_spike_tn")
+    elif (b_exact_flag is not None and b_plane is not None and N % 8 == 0 and USE_SPIKE_GEMM
+          and DENSE_GEMM == "split6"):  # (the transposed plane loads need 16-byte column groups: N % 8 == 0)
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
+        tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
+        check(lib.sparch_gemm_auto16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(b_plane),
+                                        b_plane.stride(0), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
+                                        ptr(b_exact_flag), ptr(ws), nbytes, _stream()), "sparch_gemm_auto16_tn")
     elif b_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
         nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
@@ -640,8 +671,12 @@ class SpikingLayerFn(torch.autograd.Function):
         use_bn_stats = norm == "batchnorm" and training
         in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
         # otherwise (network input): let the device decide whether x is bf16-exact (binned spike counts are)
-        xflag = flag_bf16_exact(x2) if (in_scale is None and USE_SPIKE_GEMM) else None
-        ctx.xflag = xflag
+        xplane = None
+        if in_scale is None and USE_SPIKE_GEMM and USE_SPIKE16 and USE_INPUT_PLANE and DENSE_GEMM == "split6":
+            xplane, xflag = plane_bf16_exact(x2)  # one pass: the flag AND the plane the two GEMMs read when it is 1
+        else:
+            xflag = flag_bf16_exact(x2) if (in_scale is None and USE_SPIKE_GEMM) else None
+        ctx.xflag, ctx.xplane = xflag, xplane
         x16 = cfg.get("in_spike16") if in_scale is not None else None
         x16 = x16.view(M, K) if x16 is not None else None
         # the weights' bf16 planes, split once here for backward's dx GEMM (775 -> 732 us).  The projection itself
@@ -653,7 +688,7 @@ class SpikingLayerFn(torch.autograd.Function):
         w_planes = split_planes(W) if planes_ok and (need_dx or (PRESPLIT_NT and x16 is not None)) else None
         ctx.w_planes = w_planes if need_dx else None
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale, a_exact_flag=xflag, a16=x16,
-                                  b_planes=w_planes if PRESPLIT_NT else None)  # snns.py:261
+                                  b_planes=w_planes if PRESPLIT_NT else None, a_plane=xplane)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
                                                     cfg.get("running_var"), training, dirs)  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
@@ -709,10 +744,10 @@ class SpikingLayerFn(torch.autograd.Function):
         elif in_scale is not None and USE_SPIKE_GEMM:
             dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
         else:
-            dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag)
+            dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag, b_plane=ctx.xplane)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W, b_planes=ctx.w_planes).view(B, T, K) if ctx.needs_input_grad[1] else None
-        ctx.w_planes = None
+        ctx.w_planes = ctx.xplane = None
         return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),
                 pg.get("V"), None, None, None)
 

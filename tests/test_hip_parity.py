@@ -279,6 +279,39 @@ def test_gemm_presplit_weight_planes_are_bit_identical(M, N, K):
 
 
 @pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("M,N,K", [(1000, 260, 700), (512, 1024, 40), (300, 64, 33), (2048, 256, 704)])
+def test_gemm_auto_with_the_input_plane(exact, M, N, K):
+    """sparch_plane_bf16_exact + the _auto16_ GEMMs: the check writes the bf16 plane of the network input in the
+    pass that computes the flag; with integer counts (flag 1) the GEMMs read the plane and must give the SAME bits
+    as the fp32-operand kernels, with real-valued input (flag 0) they take the six-term kernels as before."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(M + N + K + int(exact))
+    A = torch.poisson(torch.full((M, K), 0.2), generator=g) if exact else torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    G = torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, Gd, bd = A.to(DEV), W.to(DEV), G.to(DEV), bias.to(DEV)
+    plane, flag = Fn.plane_bf16_exact(Ad)
+    assert int(flag[0].item()) == (1 if exact else 0)
+    assert plane.shape == (M, (K + 7) // 8 * 8)
+    if exact:
+        assert torch.equal(plane[:, :K].float(), Ad) and float(plane[:, K:].abs().sum()) == 0.0
+    flag0 = Fn.flag_bf16_exact(Ad)
+    assert torch.equal(flag0[:1], flag[:1])
+    C0, ws0 = Fn.gemm_nt(Ad, Wd, bd, colstat=(M % 256 == 0), a_exact_flag=flag0)
+    C1, ws1 = Fn.gemm_nt(Ad, Wd, bd, colstat=(M % 256 == 0), a_exact_flag=flag, a_plane=plane)
+    assert torch.equal(C0, C1) and (ws0 is None or torch.equal(ws0, ws1))
+    ref = A.double() @ W.double().T + bias.double()
+    bound = (A.abs().double() @ W.abs().double().T + bias.abs().double()) * 2e-6 + 1e-6
+    assert bool(((C1.cpu().double() - ref).abs() <= bound).all())
+    D0 = Fn.gemm_tn(Gd, Ad, b_exact_flag=flag0)             # dW = G^T A: (N, K)
+    D1 = Fn.gemm_tn(Gd, Ad, b_exact_flag=flag, b_plane=plane)
+    assert torch.equal(D0, D1)
+    refd = G.double().T @ A.double()
+    assert bool(((D1.cpu().double() - refd).abs() <= (G.abs().double().T @ A.abs().double()) * 2e-6 + 1e-6).all())
+
+
+@pytest.mark.parametrize("exact", [True, False])
 def test_gemm_auto_device_gated_paths(exact):
     """Network-input GEMMs: the bf16-exactness flag is computed on the device and gates which of the two
     enqueued kernels runs.  Integer spike counts take the single-plane path, real-valued input the 6-term one;
