@@ -715,14 +715,16 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     } while (WALKS && (lin += wgs_here) < lin_end);  // tile loop
 }
 
+// (ld_ws: row stride of the slabs, 0 = N; the ragged-plane TN product keeps its slabs at the padded width)
 __global__ void splitk_reduce_kernel2(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
-                                      int splits, int zero_diag, int accumulate) {
+                                      int splits, int zero_diag, int accumulate, int ld_ws = 0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)M * N;
     if (i >= total) return;
     const int m = (int)(i / N), n = (int)(i % N);
+    const size_t lw = ld_ws ? (size_t)ld_ws : (size_t)N, slab = (size_t)M * lw, at = (size_t)m * lw + n;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * total + i];
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * slab + at];
     if (zero_diag && m == n) s = 0.f;
     float* c = C + (size_t)m * ldc + n;
     *c = accumulate ? (*c + s) : s;
@@ -1231,13 +1233,18 @@ extern "C" int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int ld
         !b_exact_flag)
         return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int splits = choose_splits<1>(M, N, K);
-    const size_t need = (size_t)splits * M * N * sizeof(float);
+    // A ragged width (N % 8 != 0, e.g. 700 input channels): the plane kernel's transposed 16-byte loads want whole
+    // groups of 8 columns, and the plane has them — its rows are padded with zeros to ldb16.  The product is then
+    // taken at the padded width N8 (the extra columns are zeros and are never reduced), with the slabs N8 wide.
+    const int N8 = (N + 7) & ~7;
+    if (N8 > ldb16) return SPARCH_EINVAL;
+    const int splits = choose_splits<1>(M, N8, K);
+    const size_t need = (size_t)splits * M * N8 * sizeof(float);
     if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
     SArgs g{};
-    g.A = A; g.M = M; g.N = N; g.K = K; g.lda = lda; g.scale = 1.0f;
+    g.A = A; g.M = M; g.N = N8; g.K = K; g.lda = lda; g.scale = 1.0f;
     g.a_vec = aligned16(A) && (lda % 4 == 0);
-    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.C = (float*)ws; g.ldc = N8; g.c_split_stride = (size_t)M * N8;
     g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
     g.gate = b_exact_flag; g.e_exact = 1;
     g.B = reinterpret_cast<const float*>(B16); g.ldb = ldb16;
@@ -1245,13 +1252,14 @@ extern "C" int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int ld
     g.gate_want = 1;
     int rc = launch<true, true, 1, EPI_NONE, true>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
+    g.N = N;  // the fp32 operand has exactly N columns
     g.B = B; g.ldb = ldb; g.b_vec = aligned16(B) && (ldb % 4 == 0);
     g.gate_want = 0;
     rc = launch<true, true, 2, EPI_NONE>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate, N8);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

@@ -338,9 +338,8 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b
         check(lib.sparch_gemm_spike_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
                                        float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
                                        ptr(ws), nbytes, _stream()), "sparch_gemm_spike_tn")
-    elif (b_exact_flag is not None and b_plane is not None and N % 8 == 0 and USE_SPIKE_GEMM
-          and DENSE_GEMM == "split6"):  # (the transposed plane loads need 16-byte column groups: N % 8 == 0)
-        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+    elif b_exact_flag is not None and b_plane is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, (N + 7) // 8 * 8, K)  # slabs at the plane's padded width
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
         check(lib.sparch_gemm_auto16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(b_plane),
