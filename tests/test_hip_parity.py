@@ -737,6 +737,50 @@ def test_recurrent_cell_many_row_tiles_and_chunked_launches(kind, Bp, T, H, spl)
         assert relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) <= 2e-4, k
 
 
+_HEADLINE_ORACLE = {}
+
+
+def _headline_oracle(kind, Bp):
+    """Oracle forward + autograd backward of the dyadic-V cell case at the headline launch geometry (cached per
+    test session: it is the expensive half, 134 GF forward per 256 rows)."""
+    key = (kind, Bp)
+    if key not in _HEADLINE_ORACLE:
+        Wx, p, u0, w0, s0, gs = _dyadic_cell_case(kind, Bp, 250, 1024, 7 * Bp + len(kind))
+        p = {k: v.requires_grad_(True) for k, v in p.items()}
+        Wx.requires_grad_(True)
+        ref = orc.spiking_cell(kind, Wx, p, u0, w0, s0)
+        (ref * gs).sum().backward()
+        _HEADLINE_ORACLE[key] = (Wx.detach(), {k: v.detach() for k, v in p.items()}, u0, w0, s0, gs, ref.detach(),
+                                 Wx.grad, {k: v.grad for k, v in p.items()})
+    return _HEADLINE_ORACLE[key]
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind,Bp", [("RadLIF", 256), ("RLIF", 256), ("RadLIF", 512)])
+def test_recurrent_cell_headline_launch_geometry_vs_oracle(kind, Bp, compute, request):
+    """The EXACT launch of BASELINE configs[2] / configs[4] against the oracle, not through properties: (Bp, T, H) =
+    (256, 250, 1024) — 8 row tiles x 32 column tiles, one workgroup per CU, whole-sequence launch, XCD-local
+    hand-off stores, the depth-4 sentinel ring wrapping 62 times, the backward's bulk stores one step late — and
+    (512, 250, 1024), the 16 row tiles of a bidirectional B = 256 layer.  Dyadic V (every partial sum of s @ V
+    exact in fp32 in any order): spikes torch.equal to oracle.spiking_cell over all 250 steps, so a stale or torn
+    hand-off tile anywhere in the sequence flips spikes; dWx and every parameter gradient within 2e-4 of max-abs
+    (fp32) / 2e-2 (bf16 operand mode, one rounding of dWx per product; V itself is bf16-exact here, so the
+    forward is bit-exact in that mode too).  Reference: snns.py:554-578, 696-727."""
+    Fn = _Fn()
+    if compute == "bf16":
+        request.getfixturevalue("bf16_mode")
+    Wx, p, u0, w0, s0, gs, ref, dwx_ref, g_ref = _headline_oracle(kind, Bp)
+    s, dwx, g = _run_cell(kind, Wx, p, u0, w0, s0, gs)
+    assert ref.sum() > 0
+    assert torch.equal(s, ref), float((s != ref).float().mean())
+    tol = 2e-4 if compute == "fp32" else 2e-2
+    assert bool(torch.isfinite(dwx_ref).all()) and bool(torch.isfinite(dwx).all())
+    assert relmax(dwx.numpy(), dwx_ref.numpy()) <= tol
+    for k in g_ref:
+        assert relmax(g[k].numpy(), g_ref[k].numpy()) <= tol, k
+    assert float(torch.diag(g["V"]).abs().max()) == 0.0
+
+
 def test_cell_kernels_shape_fuzz_vs_oracle():
     """All four cells over a grid of awkward shapes — 1 / 2 / 31 / 33 / 65 rows, 1 / 2 / 5 steps, 1 / 3 / 4 / 5 / 31 /
     33 / 63 / 96 / 100 units, whole-sequence and one-step launches — one after the other in one process (so that what
