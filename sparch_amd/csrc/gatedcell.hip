@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_fwd_kernel(LigruArgs a) {
         }
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_fwd_kernel(LigruArgs a) {
         }
         yp = y;
     }
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_bwd_kernel(LigruArgs a) {
         }
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_bwd_kernel(LigruArgs a) {
         cdir = cdo;
     }
     if (valid) st4(a.carry + (size_t)bp * H + unit, cdir);
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fwd_kernel(LigruArgs a) {
         }
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fwd_kernel(LigruArgs a) {
         }
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fwd_kernel(LigruArgs a) {
         }
         yp = y;
     }
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_bwd_kernel(LigruArgs a) {
                       (unsigned)((s - 1) % RING) * slot_bytes + rt_off + (unsigned)lane * 16u, a.n_ct, red, par);
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_bwd_kernel(LigruArgs a) {
                   (unsigned)(s % RING) * slot2_bytes + rt_off2 + (unsigned)lane * 16u, a.n_kg, red2, par);
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (pw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_bwd_kernel(LigruArgs a) {
         cdir = cdo;
     }
     if (valid) st4(a.carry + (size_t)bp * H + unit, cdir);
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -74,6 +74,22 @@ __device__ __forceinline__ f32x4 ld4_saved(const float* base, size_t i, bool s16
     for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32((unsigned short)(raw >> (16 * e)));
     return v;
 }
+// ... the same load with the storage type fixed at compile time, the packed form kept as it comes off the wire
+// (expanded at the use, so that nothing waits for the load where it is issued)
+template <bool S16> struct SavedRaw { typedef f32x4 type; };
+template <> struct SavedRaw<true> { typedef u32x2 type; };
+template <bool S16>
+__device__ __forceinline__ typename SavedRaw<S16>::type ld_saved_raw(const float* base, size_t i) {
+    if constexpr (S16) return *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + i);
+    else return ld4(base + i);
+}
+__device__ __forceinline__ f32x4 expand_saved(const f32x4& r) { return r; }
+__device__ __forceinline__ f32x4 expand_saved(const u32x2& r) {
+    f32x4 v;
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+    return v;
+}
 template <bool IS_U>
 __device__ __forceinline__ void st4_saved(float* base, size_t i, f32x4 v, bool s16, float theta) {
     if (!s16) { st4(base + i, v); return; }
@@ -97,9 +113,32 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // it would wait ~2 k cycles for their write-through acknowledgements.
 __device__ __forceinline__ void vm_settled() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+// The workgroup's abort flags live in LDS and are read once per step behind a barrier.  Spelled as `volatile`
+// accesses through a generic pointer they compile to FLAT loads / stores, which count on vmcnt AND lgkmcnt and
+// complete out of order — hipcc then waits `vmcnt(0) lgkmcnt(0)` behind every flag read, i.e. behind every
+// barrier of the time loops each wave sat out the acknowledgements of the previous step's bulk HBM stores and
+// of its HBM prefetch (round 3, found in the ISA).  Through an LDS-address-space pointer they are ds_read /
+// ds_write and touch lgkmcnt only.
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) void lds_void;        // LDS destination of an LDS-DMA load
+typedef __attribute__((address_space(1))) const void g_void;    // ... and its global source
+// LDS-DMA: 16 bytes per lane from the lane's own global address to lds_wave_base + 16 * lane (wave-uniform base).
+// Inline asm: the load is then absent from hipcc's wait-count bookkeeping (its own counted waits only get
+// stricter by that), and the caller guarantees a covering `s_waitcnt vmcnt` of the ISSUING wave before the data
+// is read.  M0 (the destination base) is compiler-reserved: saved and restored inside the statement
+// (cdna_hip_programming.md, inline-asm rules).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ int lds_flag_read(const int* p) { return *(const volatile lds_i32*)p; }
+__device__ __forceinline__ void lds_flag_set(int* p) { *(volatile lds_i32*)p = 1; }
+
 __device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot) {
     __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *(volatile int*)abort_slot = 1;
+    lds_flag_set(abort_slot);
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -204,7 +243,7 @@ __device__ __forceinline__ void settle_tile(u32x4 (&g)[2][2], __amdgpu_buffer_rs
             miss = still;
             if (!__any(miss != 0)) break;
             if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                *(volatile int*)abort_slot = 1;  // the status word is raised at the kernel's exit
+                lds_flag_set(abort_slot);  // the status word is raised at the kernel's exit
                 break;
             }
         }
@@ -267,7 +306,7 @@ __device__ __forceinline__ void settle_ptile(u32x4 (&g)[2][NP], __amdgpu_buffer_
             miss = still;
             if (!__any(miss != 0)) break;
             if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                *(volatile int*)abort_slot = 1;
+                lds_flag_set(abort_slot);
                 break;
             }
         }

@@ -85,6 +85,7 @@ struct RecArgs {
     // BatchNorm backward folded in (nullable): raw projection (B,T,H) + per-column statistics; the kernel then
     // also leaves sum_t dWx and sum_t dWx*xhat per (row, column) in planes 6 and 7 of dparam_ws
     const float* bn_x; const float* bn_mean; const float* bn_invstd;
+    const float* bn_src;  // backward: bn_x, or (without BatchNorm) any readable (B,T,H) range — the loop loads unconditionally
     int save16;  // u_save / w_save hold bf16 (common.h save_u16); whole-sequence launches only
     // hand-off
     u64* chan; char* ring; unsigned* status;
@@ -196,6 +197,17 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     };
     f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
     if (pw) x_next = ld4(wx_ptr(a.t_begin));
+    // The recurrent drive of the launch's FIRST step (t = 0: s0 @ V from the host; step variants: the caller's
+    // product) and the projection row of its second step are loaded HERE, not inside the loop: a global load on
+    // one path of the loop body only (round 2 had `if (t == 0) rec = ld4(rec0)`) makes hipcc's wait-count pass
+    // merge the two paths conservatively — an `s_waitcnt vmcnt(0)` behind the reduction barrier of EVERY step,
+    // where the pointwise waves then sat out the acknowledgements of the previous step's bulk HBM stores.
+    const bool first_ext = a.t_begin == 0 || EXT;
+    f32x4 rec_first = {0.f, 0.f, 0.f, 0.f}, x_second = rec_first;
+    if (first_ext) {
+        rec_first = ld4(a.rec0 + (size_t)bpc * H + colc);
+        if (pw && a.t_begin + 1 < a.t_end) x_second = ld4(wx_ptr(a.t_begin + 1));
+    }
     // Bulk HBM stores of a step are held back (12 VGPRs) and issued only after the NEXT step's poll loads:
     // vmcnt retires in order and counts stores, so stores (and the Wx prefetch) issued ahead of the poll
     // would put their HBM latency in front of the sweep.  Issued behind it they retire under the MFMA phase.
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     auto store_step = [&](int st_t, const f32x4& vs, const f32x4& vu, const f32x4& vw) {
         const int ptt = d ? (T - 1 - st_t) : st_t;
         const size_t o_s = ((size_t)b * T + ptt) * HO + (size_t)d * H + colc;
-        st4(a.s_out + o_s, vs);
+        if (a.s_out) st4(a.s_out + o_s, vs);  // the fp32 copy: only for callers that read the layer's output tensor
         if (a.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
             u32x2 h;
             h.x = (vs[0] != 0.f ? 0x3F80u : 0u) | (vs[1] != 0.f ? 0x3F800000u : 0u);
@@ -249,13 +261,19 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         PROF_STAMP(-1);
-        const f32x4 xv = x_next;
+        // this step's projection row.  (The take-over copy of the prefetch register ends up at the loop latch with
+        // an `s_waitcnt vmcnt(0)` in front of the next poll's issue.  Measured against it in one call, 40 launches
+        // each: the prefetch by LDS-DMA — no register destination, no wait anywhere but the poll's own — 0.679 vs
+        // 0.669 ms per launch, its LDS read hoisted in front of the matrix phase 0.69; 256-1024 cycles of s_sleep
+        // ahead of the first poll sweep +0.02 ms per 256.  The round-2 code, with a FLAT flag read and a
+        // conditional load in the loop body, waited vmcnt(0) behind the reduction barrier instead: 0.699.)
+        f32x4 xv;
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
 
         if (t == 0 || EXT) {
-            const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
-            rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
-            if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
+            rec[0] = rec_first.x; rec[1] = rec_first.y; rec[2] = rec_first.z; rec[3] = rec_first.w;
+            xv = x_next;
+            x_next = x_second;
         } else {
             // ---- gather the 32 x H spike bits of step t-1 (tag == t) for this wave's k-groups
             const gu64* base = (const gu64*)a.chan + ((size_t)(t - 1) * a.n_rt_total + rt) * a.n_ct * 32;
@@ -286,8 +304,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_STAMP(0);  // poll wait
-            flush_pending();
+            // (the empty asm makes the take-over a use of the prefetch register AT THIS POINT: as a plain copy the
+            // register allocator placed it at the loop latch, with a `vmcnt(0)` in front of the next poll)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = x_next[e];
             if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
+            flush_pending();
             // ---- s_{t-1} @ V on the bf16 MFMA: spikes expanded through the LDS table (lane
             //      (row li, k-half hh) takes byte 2*ks + hh of its row's 32-bit word)
             u32x4 af[KGW][2];
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         if (xcd_local && xcc_id() != my_xcc) raise_timeout(a.status, &abort_flag[t & 1]);  // moved to another XCD
         lds_barrier();
         PROF_STAMP(2);  // barrier
-        if (*(volatile int*)&abort_flag[t & 1]) break;
+        if (lds_flag_read(&abort_flag[t & 1])) break;
         if (XSTORE && t > a.t_begin) flush_staged(t - 1);  // (the barrier above ordered the staging writes)
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
         if (t > 0 && !EXT) {
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         PROF_STAMP(4);  // dropout
     }
     if (XSTORE) {  // the last step of the launch (skipped after an abort: the step is discarded anyway)
-        const bool aborted = (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]) != 0;
+        const bool aborted = (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])) != 0;
         __syncthreads();
         if (!aborted && a.t_end > a.t_begin) flush_staged(a.t_end - 1);
     } else {
@@ -448,7 +470,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 // other's stalls.  The pointwise reverse step and the stores stay on the first 256 threads.
 // NP: planes of the hand-off tiles and of V^T — 3 = exact split, six cross terms (default); 1 = the bf16 operand
 // mode: the producer rounds its dWx once, 2 KB tiles, ONE MFMA per k16-step.
-template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3>
+// S16: the saved states u / w are bf16 (common.h save_u16) — a template parameter so that every global load of the
+// time loop is ONE unconditional instruction (see `load_step`).
+template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3, bool S16 = false>
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
     // waves, which reach the second (publish) barrier only when done with them -> one buffer
@@ -456,9 +480,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NP == 3 ? NW : 1][NP == 3 ? KGW : 1][2][64];
-    // per-thread neuron constants (alpha, beta, a, b, rate gradient of the thread's 4 columns): kept in LDS
-    // and re-read each step — the 8-wave kernel's 256-register budget has no room to hold them
-    __shared__ __attribute__((aligned(16))) f32x4 pconst[7][256];  // + BatchNorm mean, invstd of the columns
+    // neuron constants (alpha, beta, a, b, rate gradient, BatchNorm mean / invstd) of the tile's 8 column quads,
+    // per direction (the rate gradient depends on it): kept in LDS and re-read each step — the 8-wave kernel's
+    // 256-register budget has no room to hold them.  (Rounds 1-2 kept a copy per THREAD: 28 KB for 1.8 KB of data.)
+    __shared__ __attribute__((aligned(16))) f32x4 pcol[7][2][8];
+    // initial states of the tile (u0, w0, s0): read by cell step 0 only — from LDS, so that the loop body holds no
+    // global load on one path only (hipcc's wait-count pass merges such paths with an `s_waitcnt vmcnt(0)`)
+    __shared__ __attribute__((aligned(16))) f32x4 first_tile[3][256];
     // running parameter-gradient partial sums (alpha, beta, a, b) of the thread's 4 columns: touched once per
     // step, off the critical path -> LDS, so that the hot loop's registers do not spill
 #if REC_ACC_REGS
@@ -513,18 +541,25 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     }
 
     float du_n[4], dw_n[4], u_t[4];
-    if (pw) {
+    if (tid < 16) {  // thread = (direction, column quad)
+        const int dq = tid >> 3, cc = min(ct * CT + (tid & 7) * 4, H - 4), dd = min(dq, a.dirs - 1);
         f32x4 c_al, c_be, c_a, c_b, c_gr;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            c_al[e] = clampf(a.alpha[colc + e], SP_ALPHA_LO, SP_ALPHA_HI);
-            c_be[e] = ADAPT ? clampf(a.beta[colc + e], SP_BETA_LO, SP_BETA_HI) : 0.f;
-            c_a[e] = ADAPT ? clampf(a.a[colc + e], SP_A_LO, SP_A_HI) : 0.f;
-            c_b[e] = ADAPT ? clampf(a.b[colc + e], SP_B_LO, SP_B_HI) : 0.f;
-            c_gr[e] = a.g_rate ? a.g_rate[(size_t)d * H + colc + e] * a.g_rate_scale : 0.0f;
+            c_al[e] = clampf(a.alpha[cc + e], SP_ALPHA_LO, SP_ALPHA_HI);
+            c_be[e] = ADAPT ? clampf(a.beta[cc + e], SP_BETA_LO, SP_BETA_HI) : 0.f;
+            c_a[e] = ADAPT ? clampf(a.a[cc + e], SP_A_LO, SP_A_HI) : 0.f;
+            c_b[e] = ADAPT ? clampf(a.b[cc + e], SP_B_LO, SP_B_HI) : 0.f;
+            c_gr[e] = a.g_rate ? a.g_rate[(size_t)dd * H + cc + e] * a.g_rate_scale : 0.0f;
         }
-        pconst[0][tid] = c_al; pconst[1][tid] = c_be; pconst[2][tid] = c_a; pconst[3][tid] = c_b; pconst[4][tid] = c_gr;
-        if (a.bn_x) { pconst[5][tid] = ld4(a.bn_mean + colc); pconst[6][tid] = ld4(a.bn_invstd + colc); }
+        pcol[0][dq][tid & 7] = c_al; pcol[1][dq][tid & 7] = c_be; pcol[2][dq][tid & 7] = c_a;
+        pcol[3][dq][tid & 7] = c_b; pcol[4][dq][tid & 7] = c_gr;
+        if (a.bn_x) { pcol[5][dq][tid & 7] = ld4(a.bn_mean + cc); pcol[6][dq][tid & 7] = ld4(a.bn_invstd + cc); }
+    }
+    if (pw && a.t_begin == 0) {
+        first_tile[0][tid] = ld4(a.u0 + (size_t)bpc * H + colc);
+        if (ADAPT) first_tile[1][tid] = ld4(a.w0 + (size_t)bpc * H + colc);
+        first_tile[2][tid] = ld4(a.s0 + (size_t)bpc * H + colc);
     }
     const bool bn = a.bn_x != nullptr;
 #pragma unroll
@@ -552,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
     }
     {
-        const f32x4 v = ld4_saved(a.u_save, ((size_t)bpc * T + (a.t_end - 1)) * H + colc, a.save16);
+        const f32x4 v = expand_saved(ld_saved_raw<S16>(a.u_save, ((size_t)bpc * T + (a.t_end - 1)) * H + colc));
         u_t[0] = v.x; u_t[1] = v.y; u_t[2] = v.z; u_t[3] = v.w;
     }
     if (tid < 2) abort_flag[tid] = 0;
@@ -569,29 +604,40 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 
     const bool drop = a.p_drop > 0.0f;
     const uint64_t seed = drop ? resolve_seed(a.seed) : 0;
-    auto load_step = [&](int t, f32x4& g, f32x4& up, f32x4& wp, f32x4& xr) {
+    // The inputs of a reverse step (incoming gradient, raw projection for BatchNorm's sums, the saved u / w of the
+    // step before) as FOUR UNCONDITIONAL loads (three without adaptation): every path through the time loop then
+    // issues the same vector-memory instructions and hipcc's counted waits are exact.  (Rounds 1-2: `if (bn)`,
+    // `if (t > 0) .. else u0`, and a width switch for bf16 saves around them — on the merged paths the wait-count
+    // pass fell back to `vmcnt(0)`, and register reuse between the arms serialized the loads.)  Without BatchNorm
+    // the host points `bn_src` at the incoming gradient (a readable range of the same extent); cell step 0 reads row 0
+    // of the saves and is given u0 / w0 from LDS at its use; bf16 saves stay packed until then (`expand_saved`).
+    typedef typename SavedRaw<S16>::type saved_raw;
+    auto load_step = [&](int t, f32x4& g, saved_raw& up, saved_raw& wp, f32x4& xr) {
         const int tt = d ? (T - 1 - t) : t;
-        g = ld4(a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc);
-        if (bn) xr = ld4(a.bn_x + ((size_t)b * T + tt) * H + colc);
-        if (t > 0) {
-            up = ld4_saved(a.u_save, ((size_t)bpc * T + (t - 1)) * H + colc, a.save16);
-            if (ADAPT) wp = ld4_saved(a.w_save, ((size_t)bpc * T + (t - 1)) * H + colc, a.save16);
-        } else {
-            up = ld4(a.u0 + (size_t)bpc * H + colc);
-            if (ADAPT) wp = ld4(a.w0 + (size_t)bpc * H + colc);
-        }
+        const float* gp = a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
+        g = ld4(gp);
+        xr = ld4(a.bn_src + ((size_t)b * T + tt) * H + colc);
+        const size_t o = ((size_t)bpc * T + (size_t)max(t - 1, 0)) * H + colc;
+        up = ld_saved_raw<S16>(a.u_save, o);
+        if (ADAPT) wp = ld_saved_raw<S16>(a.w_save, o);
     };
-    f32x4 g_nx, up_nx, wp_nx = {0.f, 0.f, 0.f, 0.f}, xr_nx = {0.f, 0.f, 0.f, 0.f};
-    f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    g_nx = up_nx = zero4;
+    f32x4 g_nx = {0.f, 0.f, 0.f, 0.f}, xr_nx = g_nx;
+    saved_raw up_nx = {}, wp_nx = {};
     if (pw) load_step(a.t_end - 1, g_nx, up_nx, wp_nx, xr_nx);
+    vm_settled();  // every prologue load is in: the loop is entered with nothing outstanding
     // (Unlike the forward, holding this kernel's fp32 stores / prefetch back until after the tag poll does
     // not pay: measured 16.8k -> 18.2k cycles per step, the deferred traffic then competes with the tile loads.)
     PROF_DECL
 
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
         PROF_STAMP(-1);
-        const f32x4 gv = g_nx, upv = up_nx, wpv = wp_nx, xrv = xr_nx;
+        const int pt = tid & 255;
+        const f32x4 gv = g_nx, xrv = xr_nx;
+        f32x4 upv = expand_saved(up_nx), wpv = expand_saved(wp_nx);
+        if (t == 0) {  // cell step 0: the initial states (LDS; filled in the prologue when the launch ends at t = 0)
+            upv = first_tile[0][pt];
+            if (ADAPT) wpv = first_tile[1][pt];
+        }
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
         // The next step's inputs (g, u, w, raw projection: HBM loads) are prefetched IN FRONT of this step's tile
@@ -599,7 +645,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // HBM round trip sits between the pointwise waves and their first k-group, `vmcnt` being in order —
         // measured 1.20 -> 1.26 ms per launch: the tiles have not landed at that point anyway, and the late loads
         // then arrive into the pointwise phase.)
-#if REC_BWD_LATE_PREFETCH
+#if REC_BWD_LATE_PREFETCH == 2
+#elif REC_BWD_LATE_PREFETCH
         if (!(t + 1 < T && !EXT) && pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 #else
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
@@ -611,10 +658,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // same order as the reference's autograd replay: bit-identical results.
         const int tt = d ? (T - 1 - t) : t;
         const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
-        const int pt = tid & 255;
         float pre_ds[4], pre_aldu[4], pre_padw[4];
         auto pre_pointwise = [&]() __attribute__((always_inline)) {
-            const f32x4 al = pconst[0][pt], pa = pconst[2][pt], pb = pconst[3][pt], gr = pconst[4][pt];
+            const f32x4 al = pcol[0][d][cq], pa = pcol[2][d][cq], pb = pcol[3][d][cq], gr = pcol[4][d][cq];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
@@ -687,7 +733,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     }
                 }
             }
-#if REC_BWD_LATE_PREFETCH
+#if REC_BWD_LATE_PREFETCH == 1
             if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 #endif
             float* rd = red[wave];
@@ -698,11 +744,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
             PROF_STAMP(1);  // per k-group: wait, split, MFMA; LDS write
         }
-        if (xcd_local && xcc_id() != my_xcc) *(volatile int*)&abort_flag[par] = 1;  // moved to another XCD
+        if (xcd_local && xcc_id() != my_xcc) lds_flag_set(&abort_flag[par]);  // moved to another XCD
         lds_barrier();
         vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
+#if REC_BWD_LATE_PREFETCH == 2
+        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#endif
         if (BXS && valid_hi && t + 1 < a.t_end) {  // the previous step's staged outputs -> HBM (upper waves)
             const int t1 = t + 1, tt1 = d ? (T - 1 - t1) : t1;
             st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
@@ -728,13 +777,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) sp[e] = (upv[e] - a.theta) > 0.0f ? 1.0f : 0.0f;
         } else {
-            const f32x4 v = ld4(a.s0 + (size_t)bpc * H + colc);
-            vm_settled();  // last step only; keeps this load's wait out of the code behind the publish stores
+            const f32x4 v = first_tile[2][pt];
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
         }
         f32x4 dwx, spv;
         float du_new[4], dw_new[4];
-        const f32x4 al = pconst[0][pt], be = pconst[1][pt];
+        const f32x4 al = pcol[0][d][cq], be = pcol[1][d][cq];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ds = pre_ds[e] + rec[e];
@@ -756,7 +804,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // second 8 bytes of that piece; the three planes of a piece are 1 KiB apart
             const unsigned piece = (unsigned)(((cq >> 2) * NP * 64 + ((cq >> 1) & 1) * 32 + r) * 16 + (cq & 1) * 8);
             const unsigned tile_off = rt_off + (unsigned)ct * PT + piece;
-            if (t > 0) {
+            {
                 u32x2 w[3];
                 if constexpr (NP == 1) {  // one nearest-even rounding (v_cvt_pk_bf16_f32)
                     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -776,7 +824,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     w[2][pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
                 }
                 }
-                const unsigned so = (unsigned)(t % RING) * slot_bytes + tile_off;
+                // (no branch around the stores: where there is nothing to publish — cell step 0 — or to reset, the
+                // offset lies beyond the buffer resource and the hardware drops the store; the instruction count
+                // of a step is then the same on every path)
+                const unsigned so = t > 0 ? (unsigned)(t % RING) * slot_bytes + tile_off : 0xFFFFF000u;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(w[p], rsrc, so + (unsigned)(p * 1024), 0, 0);
@@ -784,9 +835,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 }
             }
 #ifndef REC_NO_RESET
-            if (t + 2 < T) {
+            {
                 const u32x2 sent = {SENTINEL, SENTINEL};
-                const unsigned so = (unsigned)((t + 2) % RING) * slot_bytes + tile_off;
+                const unsigned so = t + 2 < T ? (unsigned)((t + 2) % RING) * slot_bytes + tile_off : 0xFFFFF000u;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     if (xcd_local) __builtin_amdgcn_raw_buffer_store_b64(sent, rsrc, so + (unsigned)(p * 1024), 0, 0);
@@ -833,7 +884,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             if (ADAPT) { PACC(1, pt) = v_be; PACC(2, pt) = v_a; PACC(3, pt) = v_b; }
             if (bn) {  // BatchNorm backward's column sums (dy = dWx, xhat = (x - mean) * invstd)
                 f32x4 v_dy = PACC(4, pt), v_dyx = PACC(5, pt);
-                const f32x4 mu = pconst[5][pt], is = pconst[6][pt];
+                const f32x4 mu = pcol[5][d][cq], is = pcol[6][d][cq];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v_dy[e] += dwx[e];
@@ -852,7 +903,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     }
     PROF_FLUSH(1)
     if (BXS) {  // the launch's last step is still staged (after an abort the step is discarded anyway)
-        const bool aborted = (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]) != 0;
+        const bool aborted = (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])) != 0;
         __syncthreads();
 #if !(defined(SPARCH_REC_PROF) && defined(BA_NO_BULK))
         if (!aborted && valid_hi && a.t_end > a.t_begin) {
@@ -862,13 +913,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
 #endif
     }
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (valid) {
         f32x4 v = PACC(0, tid);
         if (a.t_begin == 0) {  // last chunk of the pass: d u_t / d alpha = (q - u_t) / (1 - alpha)
-            const f32x4 al = pconst[0][tid & 255];
+            const f32x4 al = pcol[0][d][cq];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f - al[e]);
         }
@@ -1034,7 +1085,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         }
         lds_barrier();
         vm_settled();
-        if (*(volatile int*)&abort_flag[par]) break;
+        if (lds_flag_read(&abort_flag[par])) break;
         if (s > 0 && EXT) {
             const f32x4 v = ld4(a.rec_ext + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
@@ -1119,7 +1170,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
             }
         }
     }
-    if (tid == 0 && (*(volatile int*)&abort_flag[0] | *(volatile int*)&abort_flag[1]))
+    if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
         __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1227,7 +1278,8 @@ template <bool BWD, bool ADAPT, int NP = 3>
 int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
     // 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
 #define SP_LAUNCH(K, KB, NWB)                                                                        \
-    if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB, false, NP>), dim3(grid), dim3(64 * NWB), 0, st, a); \
+    if (BWD && a.save16) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB, false, NP, true>), dim3(grid), dim3(64 * NWB), 0, st, a); \
+    else if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB, false, NP, false>), dim3(grid), dim3(64 * NWB), 0, st, a); \
     else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, KB, NWB, false, NP>), dim3(grid), dim3(64 * NWB), 0, st, a);
     switch (kgw) {
         case 1: SP_LAUNCH(1, 1, 4) break;
@@ -1528,7 +1580,7 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
     r.save16 = save_bf16 != 0;
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws;
-    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd;
+    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd; r.bn_src = bn_x ? bn_x : g_out;
     r.chan = (u64*)chan; r.status = status;
     return run_rec<true>(kind, r, chan_bytes, steps_per_launch, (hipStream_t)stream);
 }
@@ -1632,7 +1684,7 @@ extern "C" int sparch_rec_cell_step_bwd(int kind, int B, int dirs, int T, int H,
     r.u_save = const_cast<float*>(u_save); r.w_save = const_cast<float*>(w_save);
     r.g_out = g_out; r.g_rate = g_rate; r.g_rate_scale = 1.0f / ((float)B * (float)T);
     r.dWx = dWx; r.s_prev16 = s_prev16; r.dparam_ws = dparam_ws; r.dwx_step = dwx_step;
-    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd;
+    r.bn_x = bn_x; r.bn_mean = bn_mean; r.bn_invstd = bn_invstd; r.bn_src = bn_x ? bn_x : g_out;
     const unsigned grid = (unsigned)(r.n_ct * r.n_rt_total);
     hipStream_t st = (hipStream_t)stream;
     if (adapt) hipLaunchKernelGGL((rec_bwd_kernel<true, 1, 4, true>), dim3(grid), dim3(256), 0, st, r);

@@ -21,8 +21,10 @@ u0, w0, s0 = (torch.rand(B, H, generator=g).to(dev) for _ in range(3))
 gs = torch.randn(B, T, H, generator=g).to(dev)
 adaptive = kind in ("adLIF", "RadLIF")
 Fn.timer.enabled = True
-for it in range(6):
-    if it == 2:
+import os
+N_IT = int(os.environ.get("REC_TIME_ITERS", "40"))
+for it in range(N_IT):
+    if it == 4:
         Fn.timer.collect()
         Fn.timer.reset()
     s = Fn.SpikingCellFn.apply(kind, 1.0, Wx, p["alpha"], p["beta"] if adaptive else None, p["a"] if adaptive else None,
