@@ -42,7 +42,10 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #define REC_BWD_XSTORE 1  /* backward: bulk stores issued one step later by the waves without pointwise state */
 #endif
 #ifndef REC_BWD_LATE_PREFETCH
-#define REC_BWD_LATE_PREFETCH 0  /* backward: next step's HBM prefetch behind the tile loads (measured: 1.20 -> 1.26 ms) */
+#define REC_BWD_LATE_PREFETCH 2  /* backward: where the next step's HBM inputs are requested — 0: loop top, in front of the tile loads (1.083 ms per launch); 1: behind the last tile load (1.057); 2: behind the reduction barrier, a pointwise phase and a publish ahead of the next tile loads (1.036; round 3, A/B in one call) */
+#endif
+#ifndef REC_FWD_UPPER_SLEEP
+#define REC_FWD_UPPER_SLEEP 0  /* forward: s_sleep units (64 cycles) of the waves without pointwise state before they poll again */
 #endif
 #ifndef REC_AHEAD
 #define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
@@ -135,6 +138,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 __device__ __forceinline__ int lds_flag_read(const int* p) { return *(const volatile lds_i32*)p; }
 __device__ __forceinline__ void lds_flag_set(int* p) { *(volatile lds_i32*)p = 1; }
+__device__ __forceinline__ void lds_flag_store(int* p, int v) { *(volatile lds_i32*)p = v; }
 
 __device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot) {
     __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

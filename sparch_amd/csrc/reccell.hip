@@ -107,8 +107,8 @@ __device__ u64 g_rec_prof[2][512][8];
         pf_t = now_;                                                                            \
     } while (0)
 #define PROF_FLUSH(which)                                                                       \
-    if (threadIdx.x == 0 && blockIdx.x < 512)                                                   \
-        for (int i_ = 0; i_ < 6; ++i_) g_rec_prof[which][blockIdx.x][i_] += pf_acc[i_];
+    if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 256)  /* wave 0, and wave 4 in slots 256.. */ \
+        for (int i_ = 0; i_ < 6; ++i_) g_rec_prof[which][blockIdx.x + (threadIdx.x ? 256 : 0)][i_] += pf_acc[i_];
 #else
 #define PROF_DECL
 #define PROF_STAMP(i)
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 
     // element ownership for the pointwise update: row r, 4 columns
     const bool pw = tid < 256;
+    const bool pw_wave = NW == 4 || wave < 4;  // the same, as a scalar (wave-uniform branches)
     const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
     const bool valid = pw && bp < a.Bp && col < H;
@@ -356,6 +357,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         PROF_STAMP(2);  // barrier
         if (lds_flag_read(&abort_flag[t & 1])) break;
         if (XSTORE && t > a.t_begin) flush_staged(t - 1);  // (the barrier above ordered the staging writes)
+        // Everything from here to the end of the step belongs to the waves that own pointwise state.  A WAVE-UNIFORM
+        // branch (round 3): until then the upper four waves of an 8-wave workgroup ran the whole update on dead
+        // values — per-thread `valid` only masked its stores — and took every other vector issue slot of the
+        // pointwise waves they share a SIMD with (stamped: 1.44 k cycles of "pointwise" on wave 4 beside 1.54 k on
+        // wave 0).  They now go straight on to the next step's poll.
+        if (pw_wave) {
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
         if (t > 0 && !EXT) {
 #pragma unroll
@@ -416,6 +423,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             if (xcd_local) __hip_atomic_store(slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(slot, granule, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
+#if !REC_FWD_UPPER_SLEEP
+        if (NW == 8) lds_barrier();  // releases the upper waves into the next step's poll (see the else branch)
+#endif
         PROF_STAMP(3);  // pointwise + publish
         if (valid) {
             const int tt = d ? (T - 1 - t) : t;
@@ -433,6 +443,21 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             } else {
                 pend_s = so; pend_u = uo; pend_w = wo;
             }
+        }
+        } else {
+            // ... but not at once: the peers' granules of this step cannot exist before their pointwise phase is
+            // over, and sweeps that must fail load the one L2 channel that holds the row tile's granule lines
+            // (measured, 40 launches each in one call: polling at once 0.70 ms per launch; 1024 / 1536 / 2048 cycles
+            // of s_sleep first 0.665 / 0.646 / 0.72 — past the pointwise phase the upper waves are late themselves;
+            // spinning on an LDS word the first wave sets when it has published 0.68: the spin takes issue slots
+            // and LDS cycles from the pointwise waves).  So they park in a second barrier that the pointwise waves
+            // join right behind their publish store: no instruction issues while a wave waits there, and the
+            // wait adapts to the cell kind and the clock.
+#if REC_FWD_UPPER_SLEEP
+            __builtin_amdgcn_s_sleep(REC_FWD_UPPER_SLEEP);
+#else
+            lds_barrier();
+#endif
         }
         pend_t = t;
         PROF_STAMP(4);  // dropout
@@ -518,6 +543,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
 
     const bool pw = tid < 256;  // threads that own a (row, 4 columns) piece of the tile's pointwise state
+    const bool pw_wave = NW == 4 || wave < 4;  // the same, as a scalar
     const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
     const bool valid = pw && bp < a.Bp && col < H;
@@ -757,6 +783,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
             *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt1) * H + col) = stage_sp[tid & 255];
         }
+        // From here to the publish barrier: the waves that own pointwise state only (a WAVE-UNIFORM branch, round 3
+        // — until then the upper four waves ran the reduction reads and the whole reverse step on dead values and
+        // took vector issue slots and LDS cycles from the pointwise waves they share a SIMD with).
+        float sp[4] = {0.f, 0.f, 0.f, 0.f}, du_new[4] = {0.f, 0.f, 0.f, 0.f}, dw_new[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dwx = {0.f, 0.f, 0.f, 0.f}, spv = dwx;
+        if (pw_wave) {
         if (t + 1 < T && EXT) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
@@ -772,7 +804,6 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         }
 
         // ---- pointwise reverse step (its rec-independent part: pre_pointwise above)
-        float sp[4];
         if (t > 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) sp[e] = (upv[e] - a.theta) > 0.0f ? 1.0f : 0.0f;
@@ -780,8 +811,6 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             const f32x4 v = first_tile[2][pt];
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
         }
-        f32x4 dwx, spv;
-        float du_new[4], dw_new[4];
         const f32x4 al = pcol[0][d][cq], be = pcol[1][d][cq];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -845,6 +874,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 }
             }
 #endif
+        }
         }
         PROF_STAMP(3);  // pointwise + tile store issue
 #ifndef REC_NO_PUBLISH_BARRIER

@@ -46,8 +46,9 @@ lib.sparch_rec_prof_read(buf.ctypes.data, 1)
 print(f"fwd+bwd wall {e0.elapsed_time(e1):.3f} ms, firing rate {float(s.mean()):.4f}")
 names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-"],
          ["first load issue", "wait+split+mfma+lds", "barrier", "pointwise+publish", "publish barrier", "stores+partial sums"]]
-for w, label in enumerate(("forward", "backward")):
-    a = buf[w, :256, :6].astype(np.float64) / T
+for w, label in [(0, "forward"), (1, "backward"), (2, "forward, wave 4"), (3, "backward, wave 4")]:
+    a = buf[w % 2, 256 * (w // 2):256 * (w // 2) + 256, :6].astype(np.float64) / T
+    w = w % 2
     print(f"{label}: cycles per step (mean over workgroups | min | max)")
     for i in range(6):
         print(f"   {names[w][i]:20s} {a[:, i].mean():9.0f} | {a[:, i].min():9.0f} | {a[:, i].max():9.0f}")
