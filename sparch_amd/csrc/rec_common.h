@@ -42,10 +42,16 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #define REC_BWD_XSTORE 1  /* backward: bulk stores issued one step later by the waves without pointwise state */
 #endif
 #ifndef REC_BWD_LATE_PREFETCH
-#define REC_BWD_LATE_PREFETCH 2  /* backward: where the next step's HBM inputs are requested — 0: loop top, in front of the tile loads (1.083 ms per launch); 1: behind the last tile load (1.057); 2: behind the reduction barrier, a pointwise phase and a publish ahead of the next tile loads (1.036; round 3, A/B in one call) */
+#define REC_BWD_LATE_PREFETCH 2  /* backward: where the next step's HBM inputs are requested — 0: loop top, in front of the tile loads (1.083 ms per launch); 1: behind the last tile load (1.057); 2: behind the reduction barrier, a pointwise phase and a publish ahead of the next tile loads (1.036; round 3, A/B in one call); 3: behind the publish barrier, with the rec-independent part of the reverse step moved behind the tile loop (1.097) */
 #endif
 #ifndef REC_FWD_UPPER_SLEEP
 #define REC_FWD_UPPER_SLEEP 0  /* forward: s_sleep units (64 cycles) of the waves without pointwise state before they poll again */
+#endif
+#ifndef REC_BWD_PARK
+#define REC_BWD_PARK 0  /* backward: the step's saved states wait in LDS instead of VGPRs (see reccell.hip; measured 1.056 vs 1.043 ms per launch, and a second k-group of tile loads in flight still spills: off) */
+#endif
+#ifndef REC_BWD_PROBE
+#define REC_BWD_PROBE 0  /* backward: probe one dword per producer sample before issuing a step's tile loads (measured with one k-group ahead: 1.117 vs 1.040 ms per launch — the probe is one more round trip; with two or more ahead the kernel spills) */
 #endif
 #ifndef REC_AHEAD
 #define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */

@@ -523,6 +523,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #endif
     __shared__ int abort_flag[2];
     __shared__ int xcd_local_flag;
+    // PARK: the saved states of a step (u_{t-1}, w_{t-1}, the raw projection) wait in LDS from the loop top to the
+    // points that use them — the spike of s_{t-1} and the parameter sums behind the publish barrier, u_t in the next
+    // step's box-car gate — instead of in 16 VGPRs across the whole tile phase (the registers a second k-group of
+    // tile loads in flight needs)
+    constexpr bool PARK = REC_BWD_PARK && NW == 8;
+    __shared__ __attribute__((aligned(16))) f32x4 park_u[PARK ? 2 : 1][PARK ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) f32x4 park_wx[PARK ? 2 : 1][PARK ? 256 : 1];
     // BXS (8-wave kernels): the step's bulk HBM stores (dWx for the GEMMs, the bf16 plane of s_{t-1}) are issued
     // by the four waves that hold NO pointwise state, one step later: the pointwise waves stage the 24 bytes per
     // thread in LDS after the publish barrier, the upper waves pick them up behind the NEXT step's reduction
@@ -615,6 +622,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     {
         const f32x4 v = expand_saved(ld_saved_raw<S16>(a.u_save, ((size_t)bpc * T + (a.t_end - 1)) * H + colc));
         u_t[0] = v.x; u_t[1] = v.y; u_t[2] = v.z; u_t[3] = v.w;
+        if (PARK && pw) park_u[a.t_end & 1][tid] = v;
     }
     if (tid < 2) abort_flag[tid] = 0;
     const unsigned my_xcc = xcc_id();
@@ -663,6 +671,11 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         if (t == 0) {  // cell step 0: the initial states (LDS; filled in the prologue when the launch ends at t = 0)
             upv = first_tile[0][pt];
             if (ADAPT) wpv = first_tile[1][pt];
+        }
+        if (PARK && pw) {
+            park_u[t & 1][pt] = upv;
+            if (ADAPT) park_wx[0][pt] = wpv;
+            if (bn) park_wx[1][pt] = xrv;
         }
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         const int par = t & 1;
@@ -722,10 +735,42 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             // made that mode's tile phase four sequential L2 round trips, 3.2 k cycles with 16 MFMAs per SIMD)
             constexpr int AHEAD = NP == 1 ? KGW : (KGW < REC_AHEAD ? KGW : REC_AHEAD);
             u32x4 raw[KGW][2][NP];  // [k-group][k16-step][plane]: MFMA A fragments as they come off the wire
+#if REC_BWD_PROBE
+            // PROBE, then burst (round 3).  A tile load issued before its producer's stores have landed returns
+            // sentinels and costs a second, serialized round trip in `settle_ptile` — which is why more than one
+            // k-group in flight at the step's start only lost time (round 2: 10.3 k -> 11.4 k cycles per step with
+            // all loads up front; 1.04 -> 1.34 ms per launch with two groups ahead): the early groups were
+            // speculative.  So a wave first watches ONE dword per sample: lane (kk, j) reads the first word that
+            // producer thread (row 2j+1, column quad j & 7) of tile kk stores into the LAST plane — 16 samples per
+            // tile from all four producer waves, 4 cache lines per probe instruction instead of 6 KiB per k-group —
+            // and issues the tile loads only when every sample has landed.  The full sentinel check of
+            // `settle_ptile` stays: a piece that is still missing then is re-loaded as before.
+            if (pw) pre_pointwise();
+            {
+                const int pk = lane >> 4, pj = lane & 15, prow = 2 * pj + 1, pcq = pj & 7;
+                const int pkg = wave + NW * pk;
+                const unsigned poff = (pk < KGW && pkg < a.n_ct)
+                    ? slot * slot_bytes + rt_off + (unsigned)pkg * PT +
+                      (unsigned)((((pcq >> 2) * NP + (NP - 1)) * 64 + ((pcq >> 1) & 1) * 32 + prow) * 16 + (pcq & 1) * 8)
+                    : 0xFFFFFF00u;  // beyond the buffer resource: reads 0, never "missing"
+                const u64 t_start = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, poff, 0, REC_LD_AUX);
+                    if (__all(v != SENTINEL)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
+                        lds_flag_set(&abort_flag[par]);
+                        break;
+                    }
+                }
+            }
+#endif
 #pragma unroll
             for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW, NP>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             PROF_STAMP(0);  // first tile load issue
+#if !REC_BWD_PROBE && REC_BWD_LATE_PREFETCH != 3
             if (pw) pre_pointwise();
+#endif
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -762,6 +807,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #if REC_BWD_LATE_PREFETCH == 1
             if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 #endif
+#if REC_BWD_LATE_PREFETCH == 3
+            if (pw) pre_pointwise();
+#endif
             float* rd = red[wave];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -788,6 +836,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // took vector issue slots and LDS cycles from the pointwise waves they share a SIMD with).
         float sp[4] = {0.f, 0.f, 0.f, 0.f}, du_new[4] = {0.f, 0.f, 0.f, 0.f}, dw_new[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 dwx = {0.f, 0.f, 0.f, 0.f}, spv = dwx;
+        f32x4 up_use = upv, ut_use = {u_t[0], u_t[1], u_t[2], u_t[3]};
+        if (PARK && pw) { up_use = park_u[t & 1][pt]; ut_use = park_u[(t + 1) & 1][pt]; }
         if (pw_wave) {
         if (t + 1 < T && EXT) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
@@ -806,7 +856,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // ---- pointwise reverse step (its rec-independent part: pre_pointwise above)
         if (t > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sp[e] = (upv[e] - a.theta) > 0.0f ? 1.0f : 0.0f;
+            for (int e = 0; e < 4; ++e) sp[e] = (up_use[e] - a.theta) > 0.0f ? 1.0f : 0.0f;
         } else {
             const f32x4 v = first_tile[2][pt];
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
@@ -815,7 +865,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ds = pre_ds[e] + rec[e];
-            const float xs = u_t[e] - a.theta;
+            const float xs = ut_use[e] - a.theta;
             float du = boxcar_gate(ds, xs) + pre_aldu[e];                     // snns.py:33-35
             if (ADAPT) du = du + pre_padw[e];
             dwx[e] = valid ? (1.0f - al[e]) * du : 0.0f;
@@ -881,6 +931,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         lds_barrier();  // the non-pointwise waves start polling only once this workgroup's own tile is on its way
 #endif
         PROF_STAMP(4);  // publish barrier
+#if REC_BWD_LATE_PREFETCH == 3
+        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#endif
         // ---- off the critical path: fp32 outputs for the following GEMMs, parameter partial sums
 #if defined(SPARCH_REC_PROF) && defined(BA_NO_BULK)  // timing ablation (no outputs): the step's HBM stores dropped
         if (false) {
@@ -898,15 +951,17 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             }
         }
         if (pw) {
+            f32x4 wp_use = wpv, xr_use = xrv;
+            if (PARK) { if (ADAPT) wp_use = park_wx[0][pt]; if (bn) xr_use = park_wx[1][pt]; }
             f32x4 v_al = PACC(0, pt), v_be, v_a, v_b;
             if (ADAPT) { v_be = PACC(1, pt); v_a = PACC(2, pt); v_b = PACC(3, pt); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float q = upv[e] - sp[e];
-                v_al[e] += du_new[e] * (q - u_t[e]);  // x 1/(1-alpha) once, at the end
+                const float q = up_use[e] - sp[e];
+                v_al[e] += du_new[e] * (q - ut_use[e]);  // x 1/(1-alpha) once, at the end
                 if (ADAPT) {
-                    v_be[e] += dw_new[e] * wpv[e];
-                    v_a[e] += dw_new[e] * upv[e];
+                    v_be[e] += dw_new[e] * wp_use[e];
+                    v_a[e] += dw_new[e] * up_use[e];
                     v_b[e] += dw_new[e] * sp[e];
                 }
             }
@@ -918,7 +973,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v_dy[e] += dwx[e];
-                    v_dyx[e] += dwx[e] * ((xrv[e] - mu[e]) * is[e]);
+                    v_dyx[e] += dwx[e] * ((xr_use[e] - mu[e]) * is[e]);
                 }
                 PACC(4, pt) = v_dy; PACC(5, pt) = v_dyx;
             }
@@ -927,7 +982,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         for (int e = 0; e < 4; ++e) {
             if (ADAPT) dw_n[e] = dw_new[e];
             du_n[e] = du_new[e];
-            u_t[e] = upv[e];
+            u_t[e] = PARK ? 0.f : upv[e];
         }
         PROF_STAMP(5);  // fp32 stores + partial sums
     }
