@@ -227,7 +227,9 @@ int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const fl
  *           Virtual row b' >= B reads Wx[b'-B, T-1-t] (time-flipped copy, never materialised).
  *   u0,w0,s0 (Bp,H)  random initial states drawn by the host in the reference's order.
  *   s_out   (B,T,H*dirs)  post-dropout output; direction d lands in features [d*H,(d+1)*H)
- *           at its ORIGINAL time index (un-flipped), as snns.py:272-275.
+ *           at its ORIGINAL time index (un-flipped), as snns.py:272-275.  NULL => not written (ABI v5): a
+ *           caller that feeds the next layer from s16_out alone saves the 4 bytes per element; at least
+ *           one of s_out / s16_out must be given.
  *   s16_out (B,T,H*dirs)  the same spikes as a bf16 plane (uint16 bit patterns: 0x3F80 where
  *           s_out != 0, else 0) for sparch_gemm_spike16_*; NULL => not written.
  *   u_save, w_save (Bp,T,H) in cell time order; needed by the backward (NULL => not saved).

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellArgs c) {
                 so[e] = s[e] * k;
                 cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
             }
-            stv<VEC>(c.s_out + o, so);
+            if (c.s_out) stv<VEC>(c.s_out + o, so);  // the fp32 copy: only for callers that read the layer's output tensor
             if (c.s16_out) {  // the same spikes as a bf16 plane (0 / 1.0) for the GEMMs that consume them
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) c.s16_out[o + e] = so[e] != 0.0f ? (uint16_t)0x3F80 : (uint16_t)0;
@@ -643,7 +643,7 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
     SPARCH_ENTER();
     if (kind != SPARCH_KIND_LIF && kind != SPARCH_KIND_ADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_ADLIF;
-    if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !Wx || !alpha || !u0 || !s0 || !s_out)
+    if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !Wx || !alpha || !u0 || !s0 || (!s_out && !s16_out))
         return SPARCH_EINVAL;
     if (adapt && (!beta || !a || !b || !w0)) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;

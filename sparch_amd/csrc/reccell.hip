@@ -1618,7 +1618,7 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2)) return SPARCH_EINVAL;
-    if (!Wx || !alpha || !vpack || !rec0 || !u0 || !s0 || !s_out || !u_save || !status) return SPARCH_EINVAL;
+    if (!Wx || !alpha || !vpack || !rec0 || !u0 || !s0 || (!s_out && !s16_out) || !u_save || !status) return SPARCH_EINVAL;
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
@@ -1719,7 +1719,7 @@ extern "C" int sparch_rec_cell_step_fwd(int kind, int B, int dirs, int T, int H,
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
     const bool adapt = kind == SPARCH_KIND_RADLIF;
     if (B <= 0 || T <= 0 || H < 4 || (H % 4) != 0 || (dirs != 1 && dirs != 2) || t < 0 || t >= T) return SPARCH_EINVAL;
-    if (!Wx || !alpha || !rec || !u0 || !s0 || !s_out || !u_save || !s_step16) return SPARCH_EINVAL;
+    if (!Wx || !alpha || !rec || !u0 || !s0 || (!s_out && !s16_out) || !u_save || !s_step16) return SPARCH_EINVAL;
     if (adapt && (!beta || !a || !b || !w0 || !w_save)) return SPARCH_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;

@@ -472,20 +472,31 @@ class _Norm:
 
 
 # ----------------------------------------------------------------------------- cells (given Wx)
-def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_drop, seed, steps_per_launch=None):
+def spike_placeholder(B, T, F, device):
+    """(B,T,F) fp32 stand-in for a spike tensor whose only consumer reads its bf16 plane: one element of storage,
+    expanded — autograd needs the edge's shape and dtype, nobody reads the values."""
+    return torch.zeros(1, dtype=torch.float32, device=device).expand(B, T, F)
+
+
+def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_drop, seed, steps_per_launch=None,
+                 want_s_out=True):
     """Run one spiking cell over the whole sequence on the device.
 
     Wx (B,T,H) raw projection (+ optional per-column scale/shift); u0/w0/s0 (B*dirs,H).
     Returns (s_out (B,T,H*dirs), count (H*dirs) int32, saved, s16) where saved feeds cell_backward and s16 is
-    s_out != 0 as a bf16 plane (or None)."""
+    s_out != 0 as a bf16 plane (or None).  want_s_out=False (round 3): the fp32 tensor is not written — s_out is
+    None — when the bf16 plane exists, i.e. for a layer whose output only feeds the next layer's spike GEMMs
+    (the reference materialises it because its next op is a dense nn.Linear, snns.py:261; here it was 4 of the
+    14 bytes a recurrent forward step stores per element)."""
     _, T, H = Wx.shape
     Bp = B * dirs
     dev = Wx.device
     k = KIND[kind]
     adaptive, recurrent = bool(k & 1), bool(k & 2)
-    s_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
     # the same spikes as a bf16 0/1 plane for the GEMMs of the next layer (rows must stay 16-byte aligned)
     s16 = torch.empty(B, T, H * dirs, dtype=torch.bfloat16, device=dev) if (USE_SPIKE_GEMM and USE_SPIKE16) else None
+    want_s_out = want_s_out or s16 is None
+    s_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev) if want_s_out else None
     L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
     # bf16 saves: the recurrent kernels take them for whole-sequence launches only (a chunked forward resumes
     # from the saved state, which must then be exact)
@@ -511,10 +522,9 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
             pp = {k_: (torch.nn.functional.pad(v, (0, H4 - H, 0, H4 - H)) if k_ == "V" else padh(v)) for k_, v in p.items()}
             s_p, count_p, saved_p, s16_p = cell_forward(kind, padh(Wx), padh(scale), padh(shift), pp, padh(u0), padh(w0),
                                                         padh(s0), B=B, dirs=dirs, theta=theta, p_drop=p_drop, seed=seed,
-                                                        steps_per_launch=steps_per_launch)
-            cut = lambda t_: t_.view(B, T, dirs, H4)[..., :H].reshape(B, T, dirs * H).contiguous()  # noqa: E731
-            return (cut(s_p), count_p.view(dirs, H4)[:, :H].reshape(-1).contiguous(), saved_p,
-                    None if s16_p is None else cut(s16_p))
+                                                        steps_per_launch=steps_per_launch, want_s_out=want_s_out)
+            cut = lambda t_: None if t_ is None else t_.view(B, T, dirs, H4)[..., :H].reshape(B, T, dirs * H).contiguous()  # noqa: E731
+            return (cut(s_p), count_p.view(dirs, H4)[:, :H].reshape(-1).contiguous(), saved_p, cut(s16_p))
         V = p["V"]
         if rec_step_path(H):
             # One launch per time step, the recurrent product s_{t-1} @ V between the steps on the exact
@@ -662,13 +672,15 @@ class SpikingLayerFn(torch.autograd.Function):
         _require_device(W, "layer parameters")
         kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
         training, theta, p_drop, seed = cfg["training"], cfg["theta"], cfg["p_drop"], cfg["seed"]
-        x = _f32c(x)
+        in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
+        plane_in = in_scale is not None and cfg.get("in_spike16") is not None and USE_SPIKE_GEMM and USE_SPIKE16
+        if not plane_in:  # (an input read through its bf16 plane may be a placeholder: never touch its values)
+            x = _f32c(x)
         B, T, K = x.shape
         H = W.shape[0]
         M = B * T
         x2 = x.view(M, K)
         use_bn_stats = norm == "batchnorm" and training
-        in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
         # otherwise (network input): let the device decide whether x is bf16-exact (binned spike counts are)
         xplane = None
         if in_scale is None and USE_SPIKE_GEMM and USE_SPIKE16 and USE_INPUT_PLANE and DENSE_GEMM == "split6":
@@ -695,7 +707,10 @@ class SpikingLayerFn(torch.autograd.Function):
         if cfg.get("states_ready") is not None:  # initial states uploaded on a side stream (snns._rand_batch)
             cfg["states_ready"]()
         s_out, count, saved, s16 = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B,
-                                                dirs=dirs, theta=theta, p_drop=p_drop, seed=seed)
+                                                dirs=dirs, theta=theta, p_drop=p_drop, seed=seed,
+                                                want_s_out=cfg.get("fp32_out", True))
+        if s_out is None:
+            s_out = spike_placeholder(B, T, H * dirs, x.device)
         inv_keep = 1.0 / (1.0 - p_drop)
         rate = count * (inv_keep / float(B * T))  # snns.py:174 on post-dropout spikes (int32 * float -> fp32, one kernel)
         ctx.cfg = cfg
@@ -759,7 +774,10 @@ class ReadoutLayerFn(torch.autograd.Function):
         _require_device(x, "input")
         _require_device(W, "layer parameters")
         norm, training = cfg["normalization"], cfg["training"]
-        x = _f32c(x)
+        plane_in = (cfg.get("in_spike_scale") is not None and cfg.get("in_spike16") is not None
+                    and USE_SPIKE_GEMM and USE_SPIKE16)
+        if not plane_in:
+            x = _f32c(x)
         B, T, K = x.shape
         C = W.shape[0]
         if C > 256:

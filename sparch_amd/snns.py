@@ -43,11 +43,22 @@ class SpikeFunctionBoxcar(torch.autograd.Function):
         return grad_spikes * inside.to(grad_spikes.dtype)
 
 
-def _tag_spikes(s, scale, s16):
+def _tag_spikes(s, scale, s16, placeholder=False):
     """Mark `s` as a spike train of ours (entries 0 or `scale`, `s16` the same spikes as a bf16 0/1 plane) so
     that the next layer can take the exact spike GEMMs.  The tag carries the tensor's version counter: an
-    in-place edit between the layers (mul_, masked fill, slice assignment) invalidates it."""
-    s._sparch_spike_tag = (s._version, tuple(s.shape), float(scale), s16)
+    in-place edit between the layers (mul_, masked fill, slice assignment) invalidates it.
+    placeholder: `s` holds no values (forward_with_rate(fp32_out=False)); the plane is the data."""
+    s._sparch_spike_tag = (s._version, tuple(s.shape), float(scale), s16, bool(placeholder))
+
+
+def materialize_spikes(s):
+    """The values of a spiking layer's output as an fp32 tensor: `s` itself, or — for the placeholder
+    SNN.forward passes between its own layers — its bf16 plane times the dropout scale (the same numbers the
+    reference's tensor holds, snns.py:278)."""
+    tag = getattr(s, "_sparch_spike_tag", None)
+    if tag is not None and len(tag) > 4 and tag[4]:
+        return tag[3].float() * tag[2]
+    return s
 
 
 def _spike_tag(x):
@@ -306,12 +317,15 @@ class _SpikingLayer(nn.Module):
         return p
 
     # ------------------------------------------------------------------ forward
-    def forward_with_rate(self, x, states=None, states_ready=None):
+    def forward_with_rate(self, x, states=None, states_ready=None, fp32_out=True):
         """Returns (spikes (B,T,H*(1+bidir)), firing_rate (H*(1+bidir),)).  Equivalent to the
         reference forward (e.g. snns.py:663-694) followed by `.mean(dim=(0,1))` (174).
         states: (u0, w0, s0) drawn ahead of time by SNN.forward (same generator, same order);
         states_ready: callable that makes the current stream wait for their upload, called after the
-        projection GEMM has been enqueued (the upload runs under it)."""
+        projection GEMM has been enqueued (the upload runs under it);
+        fp32_out=False: the caller feeds the result to another layer of this module only — the returned
+        tensor is then a placeholder of the right shape whose VALUES ARE NOT WRITTEN (the spikes travel as the
+        bf16 plane in its tag); SNN.forward uses it between its own layers."""
         Fn._require_device(x, "input")
         dirs = 2 if self.bidirectional else 1
         rows = x.shape[0] * dirs
@@ -335,6 +349,7 @@ class _SpikingLayer(nn.Module):
             "in_spike_scale": in_scale,
             "in_spike16": in_s16,  # the same spikes as a bf16 plane
             "states_ready": states_ready,
+            "fp32_out": bool(fp32_out),
         }
         if is_bn and self.training:
             self.norm.num_batches_tracked += 1
@@ -345,7 +360,9 @@ class _SpikingLayer(nn.Module):
             getattr(self, "beta", None), getattr(self, "a", None), getattr(self, "b", None),
             self.V.weight if hasattr(self, "V") else None, u0, w0, s0)
         # lets the next layer take the exact bf16-split GEMMs and read the spikes as a bf16 plane (half the bytes)
-        _tag_spikes(s, 1.0 / (1.0 - p_drop), s16 if s16.numel() else None)
+        has_plane = s16.numel() > 0
+        _tag_spikes(s, 1.0 / (1.0 - p_drop), s16 if has_plane else None,
+                    placeholder=has_plane and not fp32_out and not s.is_contiguous())
         return s, rate
 
     def forward(self, x):
@@ -444,6 +461,13 @@ class ReadoutLayer(nn.Module):
 
 
 _LAYER_CLASSES = {"LIF": LIFLayer, "adLIF": adLIFLayer, "RLIF": RLIFLayer, "RadLIF": RadLIFLayer}
+
+
+def _global_forward_hooks():
+    """True if torch.nn.modules.module has forward hooks registered for ALL modules (they would see a layer's output)."""
+    import torch.nn.modules.module as _m
+
+    return bool(getattr(_m, "_global_forward_hooks", None)) or bool(getattr(_m, "_global_forward_hooks_always_called", None))
 
 
 class SNN(nn.Module):
@@ -572,7 +596,12 @@ class SNN(nn.Module):
                     wait()
                 x = layer(x, u0=states[i])
             else:
-                x, r = layer.forward_with_rate(x, states=states[i], states_ready=wait if i == 0 else None)
+                # between two layers of ours the spikes travel as a bf16 plane: no fp32 copy (unless somebody
+                # else may look at the layer's output: forward hooks, the network's own output)
+                inner = (i + 1 < len(self.snn) and Fn.USE_SPIKE_GEMM and Fn.USE_SPIKE16
+                         and not layer._forward_hooks and not _global_forward_hooks())
+                x, r = layer.forward_with_rate(x, states=states[i], states_ready=wait if i == 0 else None,
+                                               fp32_out=not inner)
                 if wait is not None:
                     wait()  # (no-op once the first layer's call has waited)
                 rates.append(r)

@@ -1081,7 +1081,7 @@ def _run_dyadic(sp, name, monkeypatch):
     for k, lay in enumerate(list(net.snn)[:-1]):
         def wrapped(inp, states=None, orig=lay.forward_with_rate, k=k, **kw):
             s, r = orig(inp, states=states, **kw)
-            rec[k] = s.detach()
+            rec[k] = snn_mod.materialize_spikes(s).detach()  # between the network's layers: the bf16 plane
             return s, r
         lay.forward_with_rate = wrapped
     out, rates = net(x.to(DEV))
@@ -1186,6 +1186,57 @@ def test_snn_long_sequence_non_finite_gradient_mask_matches_reference(sp, monkey
         if ok.any():
             assert relmax(g[ok], g_ref[ok]) <= 2e-4, k
     assert n_bad > 0
+
+
+@pytest.mark.parametrize("kind,bidir", [("RadLIF", False), ("adLIF", True), ("RLIF", True)])
+def test_inner_layers_without_fp32_spikes_give_identical_results(sp, kind, bidir):
+    """Between two layers of an SNN the spikes travel as a bf16 plane only; the fp32 tensor of the reference
+    (snns.py:278 -> 261 of the next layer) is not written (its autograd edge is a placeholder).  A forward hook on
+    a layer makes its output observable again, so the same network with hooks takes the fp32-writing path: both
+    must give identical outputs, firing rates and parameter gradients, and the hook must see exactly the plane's
+    spikes times the dropout scale."""
+    Fn = _Fn()
+    from sparch_amd import snns as snn_mod
+    B, T, C, sizes = 12, 30, 40, [64, 96, 10]
+    torch.manual_seed(3)
+    net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.25, bidirectional=bidir).to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+
+    def run(with_hooks):
+        seen, hooks = {}, []
+        if with_hooks:
+            for k, lay in enumerate(list(net.snn)[:-1]):
+                hooks.append(lay.register_forward_hook(lambda m, i, o, k=k: seen.__setitem__(k, o.detach().clone())))
+        for lay in net.snn:
+            lay._calls = 0  # same dropout masks in both runs
+        net.zero_grad()
+        torch.manual_seed(77)
+        out, rates = net(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        Fn.check_status()
+        for h in hooks:
+            h.remove()
+        return out.detach().clone(), rates.detach().clone(), {k: v.grad.clone() for k, v in net.named_parameters()}, seen
+
+    planes = {}
+    for k, lay in enumerate(list(net.snn)[:-1]):
+        def wrapped(inp, orig=lay.forward_with_rate, k=k, **kw):
+            s, r = orig(inp, **kw)
+            planes[k] = (bool(s._sparch_spike_tag[4]), snn_mod.materialize_spikes(s).detach().clone())
+            return s, r
+        lay.forward_with_rate = wrapped
+    out_a, rates_a, g_a, _ = run(False)
+    assert all(planes[k][0] for k in planes), "inner layers should have returned placeholders"
+    planes_a = {k: v[1] for k, v in planes.items()}
+    out_b, rates_b, g_b, seen = run(True)
+    assert not any(planes[k][0] for k in planes), "hooked layers must write their fp32 output"
+    assert torch.equal(out_a, out_b) and torch.equal(rates_a, rates_b) and float(rates_a.sum()) > 0
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+    for k in seen:
+        assert torch.equal(seen[k], planes_a[k]), k
 
 
 def test_inplace_edit_between_layers_invalidates_the_spike_fast_path(sp):
