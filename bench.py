@@ -92,20 +92,22 @@ def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950
     FETCH_SIZE correction applied).  bench.py cannot run the profiler on itself; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
     with open(path) as f:
         table = json.load(f)
+    src = {"file": "profiles/" + os.path.basename(path), "commit": table.get("_meta", {}).get("commit")}
     want = {"rec_cell_bwd": "rec_bwd_kernel", "rec_cell_fwd": "rec_fwd_kernel"}
     for prefix, kname in want.items():
         if kernel_label.startswith(prefix):
             for k, v in table.items():
                 if k.startswith(kname):
-                    return v["hbm_bytes"]
-    return None
+                    return v["hbm_bytes"], src
+    return None, None
 
 
 def _cpu_model():
@@ -133,7 +135,7 @@ def cpu_baseline(state_dict, x_cpu, y_cpu):
         n_threads = len(os.sched_getaffinity(0))
     except AttributeError:
         n_threads = os.cpu_count() or 1
-    n_threads = max(1, min(n_threads, 16))  # the GPU box grants a 16-core share per GPU
+    n_threads = max(1, n_threads)  # every core of this process's affinity mask (the GPU box grants 16 per GPU)
     torch.set_num_threads(n_threads)
     Bs, T, C = 64, WORKLOAD["T"], WORKLOAD["C"]
     sizes = WORKLOAD["layer_sizes"]
@@ -161,6 +163,7 @@ def cpu_baseline(state_dict, x_cpu, y_cpu):
     ftz = one()
     torch.set_flush_denormal(False)
     return {"value": Bs * T / med, "unit": "timesteps*samples/s", "cores": n_threads, "kind": "port",
+            "rows": Bs, "rows_of_workload": WORKLOAD["B"], "affinity_cpus": n_threads,
             "cpu_model": _cpu_model(), "value_flush_denormals": Bs * T / ftz,
             "sample": f"fwd+bwd of the same RadLIF {sizes} model (the GPU run's initial parameters) on rows 0..{Bs - 1} "
                       f"of the GPU batch (B={Bs} of {WORKLOAD['B']}), T={T}, C={C}, pdrop=0, eager torch CPU oracle: "
@@ -181,8 +184,9 @@ def main():
     ap.add_argument("--compute-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="operand precision of the matrix products: fp32 = exact bf16 splits (the headline, default); "
                          "bf16 = operands rounded once, fp32 accumulation and state (BASELINE.json configs[4] names bf16)")
-    ap.add_argument("--graph", choices=["on", "off"], default="off",
-                    help="replay the whole step as one captured HIP graph (sparch_amd.graph.GraphedTrainStep)")
+    ap.add_argument("--graph", choices=["on", "off", "auto"], default="auto",
+                    help="replay the whole step as one captured HIP graph (sparch_amd.graph.GraphedTrainStep); "
+                         "auto = when the warm-up shows the host as the bound (enqueue time >= 0.8 x step time)")
     args = ap.parse_args()
     global WORKLOAD
     WORKLOAD = WORKLOADS[args.workload]
@@ -251,10 +255,49 @@ def main():
         opt.step()
         return loss
 
+    spiking = w["neuron_type"] not in ("RNN", "MLP", "LiGRU", "GRU")
+    degraded = []  # timeouts of the persistent kernels seen by this run (all ranks agree on them)
+
+    def kernels_ok(where):
+        """Collective check of the recurrent kernels' status word.  One GPU: a timeout is an error (raise, with the
+        kernel and the time step).  N > 1: every rank reports what it saw, all ranks switch to one launch per time
+        step together and the caller repeats the region — a rank that raised alone used to leave its peers
+        waiting in the next collective (round 2's "a rank exited")."""
+        if world > 1:
+            dp.sync_status(dev)
+        if not Fn.poll_status(dev):
+            return True
+        info = Fn.describe_timeout()
+        print(f"[bench] rank {rank}: {where}: persistent-kernel timeout: {info}; status word collective over "
+              f"{world} rank(s); policy {reducer.policy if reducer is not None else None}", file=sys.stderr, flush=True)
+        if world == 1:
+            raise sparch_amd._capi.SparchHipError(Fn._TIMEOUT_TEXT + "  [" + info + "]")
+        Fn.degrade(dev)
+        degraded.append(f"{where}: {info}")
+        return False
+
+    graph_mode = args.graph
+    if graph_mode == "on" and not spiking:
+        raise SystemExit("--graph on: spiking workloads only")
+    if graph_mode == "auto":  # eager warm-up first; the host is the bound when enqueueing takes (nearly) the step
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        tot = time.perf_counter() - t0
+        graph_mode = "on" if (spiking and world == 1 and enq >= 0.8 * tot) else "off"
+        graph_why = f"auto: host enqueue {1e3 * enq / 3:.2f} ms of a {1e3 * tot / 3:.2f} ms step during warm-up"
+    else:
+        graph_why = "as requested"
+        if graph_mode == "off":
+            for _ in range(args.warmup):
+                step()
     graphed = None
-    if args.graph == "on":
-        if w["neuron_type"] in ("RNN", "MLP", "LiGRU", "GRU"):
-            raise SystemExit("--graph on: spiking workloads only")
+    if graph_mode == "on":
         from sparch_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(net, opt, loss_fn, x, y, reducer=reducer,
                                    front_end=(lambda a: Fn.fbank(a, num_mel_bins=C)) if audio else None,
@@ -262,25 +305,33 @@ def main():
         run_step = graphed.step
     else:
         run_step = step
-        for _ in range(args.warmup):
+    if not kernels_ok("warm-up"):
+        for _ in range(max(1, args.warmup)):  # degraded to per-step launches: warm those up
             step()
-    Fn.check_status(dev)
-    Fn.timer.reset()
-    Fn.timer.enabled = graphed is None  # HIP events per named call exist only for eagerly launched kernels
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run_step()
-    host_dt = time.perf_counter() - t0  # host time to ENQUEUE the steps (close to dt = the host is the bound)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    Fn.timer.enabled = False
-    totals = Fn.timer.collect()
-    Fn.check_status(dev)
+        kernels_ok("warm-up after the degrade")
+
+    def timed_region():
+        Fn.timer.reset()
+        Fn.timer.enabled = graphed is None  # HIP events per named call exist only for eagerly launched kernels
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_ = run_step()
+        host_dt_ = time.perf_counter() - t0  # host time to ENQUEUE the steps (close to dt = the host is the bound)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        Fn.timer.enabled = False
+        return dt_, host_dt_, Fn.timer.collect(), loss_
+
+    dt, host_dt, totals, loss = timed_region()
+    if not kernels_ok("timed region"):  # its steps were skipped on the device: measure the degraded path instead
+        dt, host_dt, totals, loss = timed_region()
+        if not kernels_ok("timed region after the degrade"):
+            raise SystemExit("bench.py: persistent-kernel timeouts persist after degrading to per-step launches")
     roof_note = None
     if graphed is not None:
         # per-kernel durations for the roofline object: the same kernels launched eagerly (a graph replay has no
@@ -292,7 +343,7 @@ def main():
             step()
         Fn.timer.enabled = False
         totals = Fn.timer.collect()
-        Fn.check_status(dev)
+        kernels_ok("instrumented eager steps")
         roof_note = (f"timed region = {args.steps} replays of the captured step; per-kernel durations from {args.steps} "
                      "eagerly launched, HIP-event instrumented steps of the same kernels right after it")
     if world > 1:
@@ -317,9 +368,12 @@ def main():
             if bound == "mfma":
                 ach = amount / avg_s / 1e12
                 peak = PEAK_MFMA_BF16_TFLOPS if low else PEAK_MFMA_F32_TFLOPS  # bf16 mode: one bf16 MFMA per product
+                traffic, traffic_src = (None, None) if low else pmc_traffic(dom)
                 roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": None if low else pmc_traffic(dom),
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                         "avg_ms": kern[dom]["avg_ms"]}
+                if traffic_src is not None:  # a committed profile of this workload, not a live counter read
+                    roof["traffic_profile"] = traffic_src
                 k6 = None if low else bf16_issue_factor(dom)
                 if k6 is not None:  # the same time priced as what the kernel really issues: bf16 MFMAs of the
                     roof["frac_bf16_pipe"] = ach * k6 / PEAK_MFMA_BF16_TFLOPS  # exact split, vs the bf16 peak
@@ -355,17 +409,21 @@ def main():
                                    f"pdrop={w['pdrop']}, B={B}/GPU {inp} ({origin})",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "sync_bn": bool(world > 1 and args.sync_bn),
-                       "launch": "one captured HIP graph per step" if args.graph == "on" else "eager",
+                       "launch": ("one captured HIP graph per step" if graphed is not None else "eager") + f" ({graph_why})",
                        "operands": ("rounded once to bf16, fp32 accumulation / states / updates" if low else
                                     "fp32 through exact bf16 splits"),
                        "grad_allreduce": (None if reducer is None else
-                                          ("overlapped with backward" if reducer.overlap else "one collective after backward"))},
+                                          {"overlap": "all-reduce per layer, launched as its gradients appear",
+                                           "window": "all-reduce per layer, in the windows between persistent launches",
+                                           "deferred": "one collective after backward"}[reducer.policy])},
             "roofline": roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["avg_ms"] * v["launches"] / args.steps, 4) for k, v in kern.items()},
             "final_loss": final_loss,
             # host time to enqueue one step (no synchronisation inside): well below ms_per_step = the GPU is the bound
             "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
         }
+        if degraded:
+            line["degraded"] = degraded  # timeouts seen; the numbers are those of the per-step-launch path
         if note:
             line["note"] = note
         if roof_note and roof is not None:

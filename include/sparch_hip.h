@@ -41,6 +41,20 @@ extern "C" {
 #define SPARCH_ELAUNCH (-4)     /* HIP reported a launch error                        */
 #define SPARCH_ETIMEOUT (-5)    /* reported through a status word: in-kernel wait gave up */
 
+/* The status word of a device: FOUR uint32 the caller keeps zeroed.  [0] != 0: an in-kernel wait of a persistent
+ * recurrent launch gave up (SPARCH_ETIMEOUT) and the results of that training step are invalid;
+ * [1] the number of optimizer steps sparch_adam_step skipped while [0] was raised; [2] which kernel raised it
+ * (SPARCH_STATUS_*); [3] the time step, in processing order, it gave up at (0xFFFFFFFF: not recorded). */
+#define SPARCH_STATUS_WORDS 4
+#define SPARCH_STATUS_REC_FWD 1
+#define SPARCH_STATUS_REC_BWD 2
+#define SPARCH_STATUS_ANN_REC_FWD 3
+#define SPARCH_STATUS_ANN_REC_BWD 4
+#define SPARCH_STATUS_LIGRU_FWD 5
+#define SPARCH_STATUS_LIGRU_BWD 6
+#define SPARCH_STATUS_GRU_FWD 7
+#define SPARCH_STATUS_GRU_BWD 8
+
 #define SPARCH_KIND_LIF 0
 #define SPARCH_KIND_ADLIF 1
 #define SPARCH_KIND_RLIF 2
@@ -190,12 +204,15 @@ int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const flo
  * n = dup*M), write scale = gamma*invstd, shift = beta - mean*scale, save mean/invstd,
  * update running stats in place (momentum m, unbiased variance) — unless the device word
  * skip_if_nonzero (nullable; the recurrent kernels' status word) is non-zero.
+ * num_batches_tracked (nullable, ABI v5): BatchNorm1d's int64 counter, incremented by the same launch under the
+ * same guard (the reference's `norm(...)` call does it, snns.py:264; a separate host-side `+= 1` was one more
+ * kernel per layer and advanced on skipped steps too).
  * Eval (training = 0): scale/shift from running stats; colstat_ws ignored.           */
 int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const float* colstat_ws,
                        const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float momentum, float eps, int training,
                        float* scale, float* shift, float* save_mean, float* save_invstd,
-                       const uint32_t* skip_if_nonzero, void* stream);
+                       const uint32_t* skip_if_nonzero, int64_t* num_batches_tracked, void* stream);
 
 /* Column sums of dy and dy*xhat over M rows (xhat = (x-mean)*invstd), partials in ws
  * (2 * ceil(M/256) * H floats), finished into dgamma[H], dbeta[H].                   */
@@ -277,7 +294,8 @@ int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
  *   vpack   prepacked V from sparch_vpack (forward: transpose=0, backward: transpose=1)
  *   rec0    (Bp,H) = s0 * Vmasked, the t=0 recurrent drive (s0 is not binary)
  *   chan    sparch_rec_chan_bytes(Bp,T,H) bytes, zeroed by the call itself
- *   status  1 uint32, set non-zero if an in-kernel wait gave up (SPARCH_ETIMEOUT)
+ *   status  the device's status word (SPARCH_STATUS_WORDS uint32, see above): [0] set non-zero if an in-kernel
+ *           wait gave up (SPARCH_ETIMEOUT), [2] / [3] which kernel and at which step
  *   steps_per_launch: T => one persistent launch per batch-tile group; 1 => one launch
  *           per time step (no inter-workgroup waiting at all; the safe fallback).     */
 size_t sparch_vpack_bytes(int H);
@@ -514,11 +532,13 @@ int sparch_gate_step(int mode, int B, int dirs, int T, int H, int t, const float
  * scalars_dev (nullable): device float[2] = {step_size, bc2_sqrt} read instead of the two arguments — for a
  * step captured in a HIP graph, whose kernel arguments are frozen at capture time.
  * skip_if_nonzero (nullable): a device word, e.g. the recurrent kernels' status word — when it is non-zero
- * the step leaves parameters and moments untouched (a timed-out step must not be applied; no host sync). */
+ * the step leaves parameters and moments untouched (a timed-out step must not be applied; no host sync) and
+ * adds 1 to skip_if_nonzero[1] (hence not const: the caller learns how many steps to take back from its
+ * bias-correction counter when it reads the word). */
 int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                      float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
-                     float weight_decay, const float* scalars_dev, const uint32_t* skip_if_nonzero,
+                     float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                      void* stream);
 
 #ifdef __cplusplus

@@ -62,7 +62,7 @@ PROTOTYPES = {
     "sparch_gemm_auto16_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int,
                                       P, P, c_size_t, P]),
     "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
-                                   P, P, P, P, P, P]),
+                                   P, P, P, P, P, P, P]),
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sparch_bn_bwd_reduce": (c_int, [c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     "sparch_bn_bwd_apply": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P]),

@@ -8,7 +8,10 @@ void sparch_note_hip_error(int e) { g_last_hip_error = e; }
 // 3: step variants of the recurrent cells (any hidden size), BatchNorm sums out of the cell backward kernels,
 //    optional bf16 saved states, device-side skip words on adam / bn_finalize, readout up to 256 classes
 // 4: sparch_set_operand_precision (bf16 operands, fp32 accumulation) for the GEMMs and the recurrent cells
-extern "C" int sparch_abi_version(void) { return 4; }
+// 5: s_out optional in the cell forwards; the status word is SPARCH_STATUS_WORDS uint32 (raised, skipped optimizer
+//    steps, kernel id, time step); sparch_bn_finalize takes BatchNorm's num_batches_tracked; sparch_adam_step
+//    counts the steps it skips
+extern "C" int sparch_abi_version(void) { return 5; }
 
 // Process-wide operand precision of every matrix product of the library (GEMMs and the recurrent cells'
 // s @ V / dWx @ V^T): set between steps, never while launches are being enqueued from another thread.

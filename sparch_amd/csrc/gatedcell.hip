@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_fwd_kernel(LigruArgs a) {
         yp = y;
     }
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, SPARCH_STATUS_LIGRU_FWD, -1);
 }
 
 // ------------------------------------------------------------------------------ backward
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ligru_bwd_kernel(LigruArgs a) {
     }
     if (valid) st4(a.carry + (size_t)bp * H + unit, cdir);
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, SPARCH_STATUS_LIGRU_BWD, -1);
 }
 
 
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fwd_kernel(LigruArgs a) {
         yp = y;
     }
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, SPARCH_STATUS_GRU_FWD, -1);
 }
 
 // backward: vpack = ligru backward layout with [Vz ; Vr] (K = 2H: producer tile kg = 32 rows x (16 dz_pre +
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_bwd_kernel(LigruArgs a) {
     }
     if (valid) st4(a.carry + (size_t)bp * H + unit, cdir);
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, SPARCH_STATUS_GRU_BWD, -1);
 }
 
 // fragments of ONE matrix for a 16-column product on the 16x16x32 MFMA: column lane & 15 = unit ct*16 + (lane & 15),

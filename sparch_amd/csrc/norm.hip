@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int H, int M, int n_ti
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd, const uint32_t* __restrict__ skip_if_nonzero) {
+                                   float* __restrict__ save_invstd, const uint32_t* __restrict__ skip_if_nonzero,
+                                   long long* __restrict__ num_batches_tracked) {
     __shared__ double red[CS_LANES][CS_COLS];
+    if (training && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0 &&
+        !(skip_if_nonzero && *skip_if_nonzero != 0u))
+        *num_batches_tracked += 1;  // BatchNorm1d's counter (snns.py:264), under the same guard as the statistics
     const int h = blockIdx.x * CS_COLS + (threadIdx.x & (CS_COLS - 1));
     const bool ok = h < H;
     double s = 0.0, ss = 0.0;
@@ -317,13 +321,14 @@ extern "C" int sparch_bn_finalize(int H, int M, int n_tiles, int dup, const floa
                                   const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, int training,
                                   float* scale, float* shift, float* save_mean, float* save_invstd,
-                                  const uint32_t* skip_if_nonzero, void* stream) {
+                                  const uint32_t* skip_if_nonzero, int64_t* num_batches_tracked, void* stream) {
     SPARCH_ENTER();
     if (H <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return SPARCH_EINVAL;
     if (training && (M <= 0 || n_tiles <= 0 || dup < 1 || !colstat_ws)) return SPARCH_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, (hipStream_t)stream, H, M,
                        n_tiles, dup, colstat_ws, gamma, beta, running_mean, running_var, momentum, eps,
-                       training, scale, shift, save_mean, save_invstd, skip_if_nonzero);
+                       training, scale, shift, save_mean, save_invstd, skip_if_nonzero,
+                       reinterpret_cast<long long*>(num_batches_tracked));
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

@@ -26,14 +26,18 @@ struct AdamBatch {
     long long n[ADAM_MAX];
     int count;
     float step_size, beta1, beta2, bc2_sqrt, eps, weight_decay;
-    const uint32_t* skip_if_nonzero;  // device word (nullable): non-zero -> the step is a no-op
+    uint32_t* skip_if_nonzero;        // device word (nullable): non-zero -> the step is a no-op, counted in word [1]
     const float* scalars;             // device {step_size, bc2_sqrt} (nullable): overrides the two arguments
+    int count_skip;                   // this launch is the first of its step: it counts a skipped step
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
     // a recurrent kernel of this training step timed out (status word raised): its gradients are invalid,
     // leave parameters and moments untouched — no host round trip needed to protect them
-    if (a.skip_if_nonzero && *a.skip_if_nonzero != 0u) return;
+    if (a.skip_if_nonzero && *a.skip_if_nonzero != 0u) {
+        if (a.count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.skip_if_nonzero + 1, 1u);
+        return;
+    }
     int ti = 0;
     while (ti + 1 < a.count && (long long)blockIdx.x >= a.first_blk[ti + 1]) ++ti;  // uniform, <= 24 steps
     const long long base = ((long long)blockIdx.x - a.first_blk[ti]) * ADAM_CHUNK;
@@ -67,12 +71,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
 extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                                 float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                                 float step_size, float beta1, float beta2, float bc2_sqrt, float eps,
-                                float weight_decay, const float* scalars_dev, const uint32_t* skip_if_nonzero,
+                                float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                                 void* stream) {
     SPARCH_ENTER();
     if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
         return SPARCH_EINVAL;
     if (!scalars_dev && !(bc2_sqrt > 0.0f)) return SPARCH_EINVAL;
+    bool first = true;
     for (int t = 0; t < n_tensors;) {  // ONE running index: empty tensors are skipped without being counted
         AdamBatch a{};
         a.count = 0;
@@ -91,6 +96,8 @@ extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float
         if (a.count == 0) continue;
         a.step_size = step_size; a.beta1 = beta1; a.beta2 = beta2; a.bc2_sqrt = bc2_sqrt; a.eps = eps;
         a.weight_decay = weight_decay; a.skip_if_nonzero = skip_if_nonzero; a.scalars = scalars_dev;
+        a.count_skip = first ? 1 : 0;
+        first = false;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, a);
         SPARCH_CHECK_LAUNCH();
     }

@@ -146,8 +146,16 @@ __device__ __forceinline__ int lds_flag_read(const int* p) { return *(const vola
 __device__ __forceinline__ void lds_flag_set(int* p) { *(volatile lds_i32*)p = 1; }
 __device__ __forceinline__ void lds_flag_store(int* p, int v) { *(volatile lds_i32*)p = v; }
 
-__device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot) {
+// The status word of a device is FOUR uint32 (include/sparch_hip.h): [0] raised, [1] optimizer steps skipped while it
+// was raised (sparch_adam_step counts them), [2] id of the kernel that raised it (SPARCH_STATUS_*), [3] the time step
+// (processing order) it gave up at.  Diagnostics first, the flag last.
+__device__ __forceinline__ void status_raise(unsigned* status, unsigned kernel_id, int step) {
+    __hip_atomic_store((gu32*)status + 2, kernel_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu32*)status + 3, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void raise_timeout(unsigned* status, int* abort_slot, unsigned kernel_id, int step) {
+    status_raise(status, kernel_id, step);
     lds_flag_set(abort_slot);
 }
 

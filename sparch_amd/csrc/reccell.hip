@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
                 if (__all(bad == 0)) break;
                 if ((spins & 63u) == 63u &&
                     __builtin_amdgcn_s_memrealtime() - t_start > TIMEOUT_TICKS) {
-                    raise_timeout(a.status, &abort_flag[t & 1]);
+                    raise_timeout(a.status, &abort_flag[t & 1], SPARCH_STATUS_REC_FWD, t);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             }
             PROF_STAMP(1);  // expand + MFMA + LDS write
         }
-        if (xcd_local && xcc_id() != my_xcc) raise_timeout(a.status, &abort_flag[t & 1]);  // moved to another XCD
+        if (xcd_local && xcc_id() != my_xcc) raise_timeout(a.status, &abort_flag[t & 1], SPARCH_STATUS_REC_FWD, t);  // moved to another XCD
         lds_barrier();
         PROF_STAMP(2);  // barrier
         if (lds_flag_read(&abort_flag[t & 1])) break;
@@ -663,6 +663,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // not pay: measured 16.8k -> 18.2k cycles per step, the deferred traffic then competes with the tile loads.)
     PROF_DECL
 
+    int t_stop = -1;  // the step an abort was seen at (diagnostics of the status word)
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
         PROF_STAMP(-1);
         const int pt = tid & 255;
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         lds_barrier();
         vm_settled();  // tile loads are in, last step's stores and this step's prefetch long complete
         PROF_STAMP(2);  // barrier
-        if (lds_flag_read(&abort_flag[par])) break;
+        if (lds_flag_read(&abort_flag[par])) { t_stop = t; break; }
 #if REC_BWD_LATE_PREFETCH == 2
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 #endif
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #endif
     }
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, SPARCH_STATUS_REC_BWD, t_stop);
 
     if (valid) {
         f32x4 v = PACC(0, tid);
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ann_rec_kernel(AnnArgs a) {
         }
     }
     if (tid == 0 && (lds_flag_read(&abort_flag[0]) | lds_flag_read(&abort_flag[1])))
-        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status_raise(a.status, BWD ? SPARCH_STATUS_ANN_REC_BWD : SPARCH_STATUS_ANN_REC_FWD, -1);
 }
 
 // ------------------------------------------------------------------------------ V prepack

@@ -119,7 +119,7 @@ class Experiment:
         if self.world > 1:
             self.reducer = dp.GradAllReducer(self.net, rows_per_rank=self.batch_size // self.world)
             logging.info(f"Gradient all-reduce: {self.reducer.bytes_per_step / 1e6:.2f} MB per step, "
-                         f"{'overlapped with backward' if self.reducer.overlap else 'one collective after backward'}")
+                         f"policy '{self.reducer.policy}' (sparch_amd/dp.py)")
             if self.sync_bn:
                 Fn.SYNC_BN = {"group": None, "world": self.world}
                 logging.info("BatchNorm statistics are exchanged between ranks (--sync_bn)")
@@ -325,12 +325,26 @@ class Experiment:
         not become co-resident: GPU shared or partitioned) the steps since the last check were no-ops on the
         device (the optimizer and the BatchNorm statistics skip themselves while the word is raised); this
         process now continues with one launch per time step — new launches, same process."""
-        if check_status(self.device, on_timeout="degrade"):
-            logging.warning(f"Epoch {e}, step {step}: {Fn._TIMEOUT_TEXT}  Steps since the previous check were "
-                            "skipped; continuing with one kernel launch per time step "
+        if self._timeout_on_any_rank():
+            logging.warning(f"Epoch {e}, step {step}: {Fn._TIMEOUT_TEXT}  [{Fn.describe_timeout()}]  Steps since the "
+                            "timeout were skipped on every rank; continuing with one kernel launch per time step "
                             "(SPARCH_REC_STEPS_PER_LAUNCH=1 behaviour).")
 
-    def _eval_epoch(self, loader):
+    def _timeout_on_any_rank(self):
+        """Collective read of the status word: every rank sees the MAX over ranks (the reducer already merges it
+        every training step; evaluation has no reducer), so all ranks degrade together — a rank that raised
+        alone used to leave its peers waiting in the next collective.  After a degrade the replicas are
+        re-synchronised from rank 0 (they skipped the same steps, so this is a safety net, not a repair)."""
+        if self.world > 1:
+            dp.sync_status(self.device)
+        if not check_status(self.device, on_timeout="degrade"):
+            return False
+        if self.world > 1:
+            for t in list(self.net.parameters()) + list(self.net.buffers()):
+                torch.distributed.broadcast(t.data, src=0)
+        return True
+
+    def _eval_epoch(self, loader, retried=False):
         losses, accs, sizes = [], [], []
         epoch_spike_rate = 0
         step = 0
@@ -343,7 +357,12 @@ class Experiment:
             sizes.append(y.shape[0])
             if self.net.is_snn:
                 epoch_spike_rate += torch.mean(firing_rates)
-        check_status(self.device)
+        if self._timeout_on_any_rank():  # the epoch's numbers are invalid: once more, now with per-step launches
+            if retried:
+                raise Fn._capi.SparchHipError(Fn._TIMEOUT_TEXT + "  [" + Fn.describe_timeout() + "]")
+            logging.warning(f"Evaluation: {Fn._TIMEOUT_TEXT}  [{Fn.describe_timeout()}]  Repeating the epoch with one "
+                            "kernel launch per time step.")
+            return self._eval_epoch(loader, retried=True)
         losses = torch.stack(losses).cpu().numpy().astype(np.float64) if losses else np.zeros(0)
         accs = (torch.stack(accs).cpu().numpy().astype(np.float64) / np.asarray(sizes, np.float64)) if accs else np.zeros(0)
         if self.net.is_snn:

@@ -82,6 +82,26 @@ B_LIM = (0.0, 2.0)  # snns.py:359
 
 _status = {}
 
+# Objects with pre_persistent() / post_persistent(), called right before / right behind every persistent recurrent
+# launch (kernels whose workgroups wait for each other and need the whole GPU): sparch_amd.dp's "window" policy
+# keeps its collectives out of those kernels' way with them.
+persistent_hooks = []
+
+
+class _persistent_launch:
+    """with _persistent_launch(): <enqueue one persistent kernel>"""
+
+    def __enter__(self):
+        for h in persistent_hooks:
+            h.pre_persistent()
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            for h in persistent_hooks:
+                h.post_persistent()
+        return False
+
+
 
 class KernelTimer:
     """Optional HIP-event timing of named C-ABI calls on the current stream (bench.py uses it for
@@ -149,13 +169,42 @@ _TIMEOUT_TEXT = (
 _degraded = set()  # device indices whose recurrent kernels now run one launch per time step
 
 
+STATUS_KERNELS = {0: "?", 1: "rec_fwd (RLIF / RadLIF forward)", 2: "rec_bwd (RLIF / RadLIF backward)",
+                  3: "ann_rec forward (RNN)", 4: "ann_rec backward (RNN)", 5: "ligru forward", 6: "ligru backward",
+                  7: "gru forward", 8: "gru backward"}  # include/sparch_hip.h SPARCH_STATUS_*
+last_timeout = None   # details of the most recent timeout poll_status() saw: dict(kernel, step, skipped_steps)
+_timeout_listeners = []  # callables(info) — e.g. the optimizer takes its step counter back by info["skipped_steps"]
+
+
 def poll_status(device="cuda"):
-    """Synchronising read of the persistent-kernel status word; clears it.  True = a wait timed out."""
+    """Synchronising read of the persistent-kernel status word (4 x uint32: raised, optimizer steps skipped since,
+    kernel id, time step); clears it.  True = a wait timed out; the details are left in `last_timeout` and handed
+    to the registered listeners."""
+    global last_timeout
     w = status_word(device)
-    if int(w[0].item()) != 0:
+    vals = w.tolist()
+    if vals[0] != 0:
         w.zero_()
+        step = vals[3] & 0xFFFFFFFF
+        last_timeout = {"kernel": STATUS_KERNELS.get(vals[2], f"kernel id {vals[2]}"),
+                        "step": None if step == 0xFFFFFFFF else step, "skipped_steps": int(vals[1]),
+                        "device": str(w.device)}
+        for fn in list(_timeout_listeners):
+            fn(last_timeout)
         return True
     return False
+
+
+def describe_timeout():
+    """One line about the most recent timeout (which kernel, which time step, how many optimizer steps were skipped)."""
+    if last_timeout is None:
+        return "no timeout recorded"
+    t = last_timeout
+    import os as _os
+    rank = _os.environ.get("RANK")
+    return (f"{'rank ' + rank + ', ' if rank is not None else ''}{t['device']}: {t['kernel']} gave up"
+            f"{'' if t['step'] is None else ' at time step ' + str(t['step'])}; "
+            f"{t['skipped_steps']} optimizer step(s) were skipped on the device since")
 
 
 def degrade(device="cuda"):
@@ -173,8 +222,8 @@ def check_status(device="cuda", on_timeout="raise"):
     if on_timeout == "degrade":
         degrade(device)
         return True
-    raise _capi.SparchHipError(_TIMEOUT_TEXT + "  Set SPARCH_REC_STEPS_PER_LAUNCH=1 (one launch per time step, "
-                               "no waiting inside) to run on a shared GPU.")
+    raise _capi.SparchHipError(_TIMEOUT_TEXT + "  [" + describe_timeout() + "]  Set SPARCH_REC_STEPS_PER_LAUNCH=1 "
+                               "(one launch per time step, no waiting inside) to run on a shared GPU.")
 
 
 def rec_steps_per_launch(T):
@@ -394,7 +443,9 @@ class _Norm:
     (scale, shift) consumed by the cell kernel; LayerNorm materialises the normalised tensor."""
 
     @staticmethod
-    def forward(mode, Wx_raw, colstat, weight, bias, running_mean, running_var, training, dup):
+    def forward(mode, Wx_raw, colstat, weight, bias, running_mean, running_var, training, dup, nbt=None):
+        """nbt: BatchNorm's num_batches_tracked (int64 device tensor) — incremented by the finalize kernel itself,
+        under the status-word guard, instead of by a separate host-side `+= 1` (None: the caller keeps doing that)."""
         M, H = Wx_raw.shape
         dev = Wx_raw.device
         if mode == "batchnorm":
@@ -414,7 +465,7 @@ class _Norm:
             check(lib.sparch_bn_finalize(H, rows, n_tiles, dup, ptr(colstat), ptr(weight), ptr(bias),
                                          ptr(running_mean), ptr(running_var), BN_MOMENTUM, NORM_EPS,
                                          int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                         ptr(status_word(dev)), _stream()), "sparch_bn_finalize")
+                                         ptr(status_word(dev)), ptr(nbt), _stream()), "sparch_bn_finalize")
             return Wx_raw, scale, shift, (mean, invstd)
         if mode == "layernorm":
             y = torch.empty_like(Wx_raw)
@@ -556,11 +607,12 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
         chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
         tok = timer.start(f"rec_cell_fwd[{kind}]")
-        check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
-                                      ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
-                                      ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
-                                      ptr(s16), ptr(u_save), ptr(w_save), int(save16), ptr(count), ptr(chan),
-                                      nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
+        with _persistent_launch():
+            check(lib.sparch_rec_cell_fwd(k, B, dirs, T, H, ptr(Wx), ptr(scale), ptr(shift), ptr(p["alpha"]),
+                                          ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
+                                          ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
+                                          ptr(s16), ptr(u_save), ptr(w_save), int(save16), ptr(count), ptr(chan),
+                                          nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
         timer.stop(tok)
         return s_out, count, (u_save, w_save, vpack_t), s16
     return s_out, count, (u_save, w_save), s16
@@ -630,11 +682,12 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
             tok = timer.start(f"rec_cell_bwd[{kind}]")
-            check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
-                                          int(save16), ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
-                                          ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
-                                          ptr(s_prev), ptr(ws), ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(chan),
-                                          nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_bwd")
+            with _persistent_launch():
+                check(lib.sparch_rec_cell_bwd(k, B, dirs, T, H, ptr(g_out), ptr(g_rate), ptr(u_save), ptr(w_save),
+                                              int(save16), ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
+                                              ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
+                                              ptr(s_prev), ptr(ws), ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(chan),
+                                              nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_bwd")
             timer.stop(tok)
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
         # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
@@ -701,7 +754,8 @@ class SpikingLayerFn(torch.autograd.Function):
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=use_bn_stats, spike_scale=in_scale, a_exact_flag=xflag, a16=x16,
                                   b_planes=w_planes if PRESPLIT_NT else None, a_plane=xplane)  # snns.py:261
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
-                                                    cfg.get("running_var"), training, dirs)  # 264-266
+                                                    cfg.get("running_var"), training, dirs,
+                                                    nbt=cfg.get("num_batches_tracked"))  # 264-266
         p = {"alpha": alpha, "beta": beta, "a": a, "b": b, "V": V}
         p = {k_: v for k_, v in p.items() if v is not None}
         if cfg.get("states_ready") is not None:  # initial states uploaded on a side stream (snns._rand_batch)
@@ -789,7 +843,8 @@ class ReadoutLayerFn(torch.autograd.Function):
                                   spike_scale=cfg.get("in_spike_scale"),
                                   a16=x16.view(M, K) if x16 is not None else None)  # snns.py:796
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
-                                                    cfg.get("running_var"), training, 1)  # 799-801
+                                                    cfg.get("running_var"), training, 1,
+                                                    nbt=cfg.get("num_batches_tracked"))  # 799-801
         out = torch.empty(B, C, dtype=torch.float32, device=x.device)
         u_save = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
         check(lib.sparch_readout_fwd(B, T, C, ptr(Wx_in), ptr(scale), ptr(shift), ptr(alpha), ptr(u0), ptr(out),
@@ -1068,10 +1123,11 @@ class RNNLayerFn(torch.autograd.Function):
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_fwd[RNN]")
-            check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
-                                         ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state),
-                                         ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T),
-                                         _stream()), "sparch_ann_rec_fwd")
+            with _persistent_launch():
+                check(lib.sparch_ann_rec_fwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(Wx_in), ptr(scale), ptr(shift),
+                                             ptr(vpack), cfg["p_drop"], cfg["seed"], ptr(y_out), ptr(y_state),
+                                             ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T),
+                                             _stream()), "sparch_ann_rec_fwd")
             timer.stop(tok)
         ctx.cfg, ctx.shape, ctx.nsaved = cfg, (B, T, K, H), nsaved
         ctx.save_for_backward(x2, W, nw, V, y_state, Wx_raw if norm in ("batchnorm", "layernorm") else None)
@@ -1105,10 +1161,11 @@ class RNNLayerFn(torch.autograd.Function):
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_bwd[RNN]")
-            check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(g_y), ptr(y_state), ptr(vpack),
-                                         cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
-                                         ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
-                  "sparch_ann_rec_bwd")
+            with _persistent_launch():
+                check(lib.sparch_ann_rec_bwd(ACT_KIND[cfg["act"]], B, dirs, T, H, ptr(g_y), ptr(y_state), ptr(vpack),
+                                             cfg["p_drop"], cfg["seed"], ptr(dpre), ptr(y_prev), ptr(chan), nbytes,
+                                             ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                      "sparch_ann_rec_bwd")
             timer.stop(tok)
         # dV[i][j] = sum over rows and steps of dpre[.,i] * y_{t-1}[.,j]   (V(y) = y V^T, anns.py:336)
         dV = gemm_tn(dpre.view(Bp * T, H), y_prev.view(Bp * T, H))
@@ -1198,12 +1255,13 @@ class GatedLayerFn(torch.autograd.Function):
             nbytes = lib.sparch_gru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("gru_fwd")
-            check(lib.sparch_gru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
-                                     ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]),
-                                     ptr(proj["r"]["z_in"]), ptr(proj["r"]["sc"]), ptr(proj["r"]["sh"]), ptr(vg), ptr(vc),
-                                     p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
-                                     ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
-                  "sparch_gru_fwd")
+            with _persistent_launch():
+                check(lib.sparch_gru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
+                                         ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]),
+                                         ptr(proj["r"]["z_in"]), ptr(proj["r"]["sc"]), ptr(proj["r"]["sh"]), ptr(vg), ptr(vc),
+                                         p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
+                                         ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                      "sparch_gru_fwd")
             timer.stop(tok)
         elif persistent:
             # the whole time loop in one persistent launch per row-tile group (gatedcell.hip)
@@ -1212,11 +1270,12 @@ class GatedLayerFn(torch.autograd.Function):
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ligru_fwd")
-            check(lib.sparch_ligru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
-                                       ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]), ptr(vp),
-                                       p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(c_save), ptr(chan),
-                                       nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
-                  "sparch_ligru_fwd")
+            with _persistent_launch():
+                check(lib.sparch_ligru_fwd(B, dirs, T, H, ptr(proj["c"]["z_in"]), ptr(proj["c"]["sc"]), ptr(proj["c"]["sh"]),
+                                           ptr(proj["z"]["z_in"]), ptr(proj["z"]["sc"]), ptr(proj["z"]["sh"]), ptr(vp),
+                                           p_drop, seed, ptr(y_out), ptr(y_state), ptr(z_save), ptr(c_save), ptr(chan),
+                                           nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                      "sparch_ligru_fwd")
             timer.stop(tok)
         else:
             tok = timer.start(f"gated_fwd[{kind}]")
@@ -1269,10 +1328,11 @@ class GatedLayerFn(torch.autograd.Function):
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)
             tok = timer.start("gru_bwd")
-            check(lib.sparch_gru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
-                                     ptr(vg), ptr(vc), p_drop, seed, ptr(d_all["z"]), ptr(d_all["r"]), ptr(d_all["c"]),
-                                     ptr(yprev_all), ptr(ry_all), ptr(carry), ptr(chan), nbytes, ptr(status_word(dev)),
-                                     rec_steps_per_launch(T), _stream()), "sparch_gru_bwd")
+            with _persistent_launch():
+                check(lib.sparch_gru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(r_save), ptr(c_save),
+                                         ptr(vg), ptr(vc), p_drop, seed, ptr(d_all["z"]), ptr(d_all["r"]), ptr(d_all["c"]),
+                                         ptr(yprev_all), ptr(ry_all), ptr(carry), ptr(chan), nbytes, ptr(status_word(dev)),
+                                         rec_steps_per_launch(T), _stream()), "sparch_gru_bwd")
             timer.stop(tok)
         elif kind == "LiGRU" and ligru_persistent_ok(H):
             vpb = torch.empty(lib.sparch_ligru_vpack_bytes(H, 1) // 4, dtype=torch.float32, device=dev)
@@ -1281,10 +1341,11 @@ class GatedLayerFn(torch.autograd.Function):
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)
             tok = timer.start("ligru_bwd")
-            check(lib.sparch_ligru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(c_save), ptr(vpb),
-                                       p_drop, seed, ptr(d_all["z"]), ptr(d_all["c"]), ptr(yprev_all), ptr(carry),
-                                       ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
-                  "sparch_ligru_bwd")
+            with _persistent_launch():
+                check(lib.sparch_ligru_bwd(B, dirs, T, H, ptr(_f32c(g_y)), ptr(y_state), ptr(z_save), ptr(c_save), ptr(vpb),
+                                           p_drop, seed, ptr(d_all["z"]), ptr(d_all["c"]), ptr(yprev_all), ptr(carry),
+                                           ptr(chan), nbytes, ptr(status_word(dev)), rec_steps_per_launch(T), _stream()),
+                      "sparch_ligru_bwd")
             timer.stop(tok)
         else:
             carry_mv = carry_dir = None

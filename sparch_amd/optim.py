@@ -32,6 +32,34 @@ class Adam(torch.optim.Optimizer):
         if amsgrad:
             raise NotImplementedError("sparch_amd.optim.Adam: amsgrad is not implemented (the reference does not use it)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        # Steps the device skipped after a persistent kernel's timeout (status word raised: sparch_adam_step is a
+        # no-op and counts itself in status[1]) are taken back from the bias-correction counters when the host
+        # reads the word, so that "a skipped step is a no-op" also holds for t in 1 - beta^t.
+        import weakref
+
+        from . import functional as _Fn
+        ref = weakref.ref(self)
+
+        def _on_timeout(info, ref=ref):
+            opt = ref()
+            if opt is None:
+                _Fn._timeout_listeners.remove(_on_timeout)
+            else:
+                opt.take_back(info["skipped_steps"])
+        _Fn._timeout_listeners.append(_on_timeout)
+
+    def take_back(self, n):
+        """Undo the step-counter advance of `n` optimizer steps that were no-ops on the device."""
+        if n <= 0:
+            return
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    st["step"] -= min(float(n), float(st["step"]))
+        g = getattr(self, "_g", None)
+        if g is not None:
+            g["t"].sub_(float(n)).clamp_(min=0.0)
 
     def enable_graph_mode(self):
         """Keep the per-step factors (lr / (1 - beta1^t), sqrt(1 - beta2^t)) in DEVICE memory, computed by a few

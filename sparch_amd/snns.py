@@ -38,9 +38,14 @@ class SpikeFunctionBoxcar(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_spikes):
+        # the reference ASSIGNS zeros outside the box (snns.py:33-35): a non-finite upstream gradient is cleared
+        # there, and a NaN x (both comparisons false) lets the gradient through — as the cell kernels do
+        # (csrc/common.h boxcar_gate) and oracle/snn_oracle.py
         (x,) = ctx.saved_tensors
-        inside = (x > -0.5) & (x <= 0.5)
-        return grad_spikes * inside.to(grad_spikes.dtype)
+        grad_x = grad_spikes.clone()
+        grad_x[x <= -0.5] = 0
+        grad_x[x > 0.5] = 0
+        return grad_x
 
 
 def _tag_spikes(s, scale, s16, placeholder=False):
@@ -277,6 +282,11 @@ class _SpikingLayer(nn.Module):
         self._calls = 0
         self._layer_index = 0  # set by SNN; decorrelates dropout masks between layers
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_seed_word", None)  # graph mode's device-side dropout seed: a step's state, not the network's
+        return state
+
     # ------------------------------------------------------------------ helpers
     @property
     def uses_persistent_kernel(self):
@@ -350,9 +360,9 @@ class _SpikingLayer(nn.Module):
             "in_spike16": in_s16,  # the same spikes as a bf16 plane
             "states_ready": states_ready,
             "fp32_out": bool(fp32_out),
+            # BatchNorm1d's counter: advanced by the statistics kernel (no separate launch; not on skipped steps)
+            "num_batches_tracked": self.norm.num_batches_tracked if (is_bn and self.training) else None,
         }
-        if is_bn and self.training:
-            self.norm.num_batches_tracked += 1
         nw = self.norm.weight if self.normalize else None
         nb = self.norm.bias if self.normalize else None
         s, rate, s16 = Fn.SpikingLayerFn.apply(
@@ -447,9 +457,8 @@ class ReadoutLayer(nn.Module):
             "running_var": self.norm.running_var if is_bn else None,
             "in_spike_scale": in_scale,
             "in_spike16": in_s16,  # the same spikes as a bf16 plane
+            "num_batches_tracked": self.norm.num_batches_tracked if (is_bn and self.training) else None,
         }
-        if is_bn and self.training:
-            self.norm.num_batches_tracked += 1
         nw = self.norm.weight if self.normalize else None
         nb = self.norm.bias if self.normalize else None
         return Fn.ReadoutLayerFn.apply(cfg, x, self.W.weight, self.W.bias, nw, nb, self.alpha, u0)
@@ -522,7 +531,7 @@ class SNN(nn.Module):
         """Every layer's initial states for one forward, drawn from torch's global CPU generator in the
         reference's order (per hidden layer u, [w], s; then the readout's u): a list with one (u0, w0, s0)
         tuple per hidden layer and the readout's u0 tensor last.  out: the flat buffer of an earlier call
-        (`self._state_flat`) to refill in place."""
+        (`.flat` of its result) to refill in place."""
         last = self.num_layers - 1
         shapes, plan = [], []
         for i, layer in enumerate(self.snn):
@@ -535,7 +544,6 @@ class SNN(nn.Module):
                 shapes += [(rows, layer.hidden_size)] * (3 if adaptive else 2)
                 plan.append(adaptive)
         batch_list = _rand_batch(shapes, device, out=out)  # one staging buffer, one copy for the whole forward
-        self._state_flat = batch_list.flat
         drawn = iter(batch_list)
         states = []
         for adaptive in plan:
@@ -547,6 +555,14 @@ class SNN(nn.Module):
                 states.append((u0, w0, next(drawn)))
         states = _StateList(states, batch_list.flat, batch_list.ready)
         return states
+
+    def __getstate__(self):
+        """Whole-module checkpoints (`torch.save(self.net)`, exp.py:462) hold the network, not a step's transient
+        device state: the static states of a captured step (an event handle among them) stay out."""
+        state = dict(self.__dict__)
+        for k in ("_static_states", "_state_flat"):
+            state.pop(k, None)
+        return state
 
     def draw_states_into(self, static_states, batch):
         """The same draws (same generator, same order) written into the EXISTING device tensors `static_states`

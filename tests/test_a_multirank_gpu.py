@@ -35,6 +35,12 @@ def test_two_ranks_on_one_gpu_gradients_and_syncbn():
                 q.kill()
             raise
         outs.append(out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    for rank, out in enumerate(outs):  # both ranks' complete output is kept (a copy goes under profiles/)
+        with open(os.path.join(ROOT, "gpurun_out", f"dp_two_ranks_one_gpu_rank{rank}.log"), "w") as f:
+            f.write(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-4000:]}"
         assert "data-parallel checks passed" in out
+        assert "forced overlap on a full grid finished" in out
+        assert "a timeout on one rank skips the step on both" in out

@@ -36,7 +36,7 @@ def test_prototype_arity_matches_header():
 
 def test_host_only_entry_points():
     lib = _capi.lib
-    assert lib.sparch_abi_version() == 4
+    assert lib.sparch_abi_version() == 5
     assert _capi.strerror(0) == "ok" and "workspace" in _capi.strerror(-3)
     assert lib.sparch_fbank_frames(16000) == 98 and lib.sparch_fbank_frames(399) == 0
     assert lib.sparch_vpack_bytes(1024) == 1024 * 1024 * 6   # three bf16 planes per fp32 element

@@ -25,7 +25,7 @@ def relmax(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-6))
 
 
-def grads_of(net, x, y, seed, reducer=None):
+def grads_of(net, x, y, seed, reducer=None, check=True):
     net.zero_grad(set_to_none=True)
     for lay in net.snn:
         lay._calls = 0
@@ -34,7 +34,8 @@ def grads_of(net, x, y, seed, reducer=None):
     torch.nn.functional.cross_entropy(out, y).backward()
     if reducer is not None:
         reducer.finish()
-    Fn.check_status()
+    if check:
+        Fn.check_status()
     return out.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()}
 
 
@@ -59,21 +60,119 @@ def main():
         state = {k: v.clone() for k, v in net.state_dict().items()}
         shard.append(grads_of(net, dp.shard_batch(x_all, r, world), dp.shard_batch(y_all, r, world), 100 + r)[1])
         net.load_state_dict(state)
-    for overlap in (False, True):
+    for policy in dp.POLICIES:
         state = {k: v.clone() for k, v in net.state_dict().items()}
-        red = dp.GradAllReducer(net, overlap=overlap, rows_per_rank=B // world)
+        red = dp.GradAllReducer(net, policy=policy, rows_per_rank=B // world, trace=True)
         _, got = grads_of(net, xs, ys, 100 + rank, red)
+        if policy == "window":  # no collective inside or across a persistent launch (tests/test_cli_and_dp.py's rule)
+            inflight, inside = set(), False
+            for what, i in red.trace:
+                if what == "pre":
+                    inside = True
+                elif what == "post":
+                    assert not inflight, red.trace
+                    inside = False
+                elif what == "launch":
+                    assert not inside, red.trace
+                    inflight.add(i)
+                elif what == "wait":
+                    inflight.discard(i)
+            assert sum(1 for what, _ in red.trace if what == "post") >= 4  # two recurrent layers, forward and backward
         red.remove()
         net.load_state_dict(state)
         for k in got:
             ref = (shard[0][k] + shard[1][k]) / 2
             e = relmax(got[k], ref)
-            assert e <= 1e-6, (overlap, k, e)
-    # default policy: this small batch leaves CUs free -> overlapped; a batch that fills the GPU -> deferred
-    assert dp.GradAllReducer(net, rows_per_rank=B // world).overlap is True
-    big = sparch_amd.SNN((256, None, C), [1024, 1024, 20], neuron_type="RadLIF")
-    assert dp.GradAllReducer(big, rows_per_rank=256).overlap is False
-    assert dp.GradAllReducer(big, rows_per_rank=64).overlap is True
+            assert e <= 1e-6, (policy, k, e)
+    # default policy: models on the persistent kernels keep their collectives in the windows between those launches
+    r_ = dp.GradAllReducer(net, rows_per_rank=B // world)
+    assert r_.policy == "window"
+    r_.remove()
+
+    # ---- 1b. the case the policy exists to avoid, FORCED: two ranks whose persistent grids each want every CU of
+    #          the one GPU they share (8 row tiles x 32 column tiles = 256 workgroups), collectives launched freely
+    #          under backward (policy "overlap" = SPARCH_DP_OVERLAP=1).  Whatever the hardware does with two such
+    #          grids — run them one after the other, or starve one until its bounded spin gives up — the step
+    #          must END: a timeout on either rank reaches both through the collective status word, both switch
+    #          to one launch per time step, repeat the step, and the averaged gradients are right.
+    Bb, Tb = 256, 12
+    gb = torch.Generator().manual_seed(21)
+    xb = (torch.rand(world * Bb, Tb, C, generator=gb) < 0.2).float().to(dev)
+    yb = torch.randint(0, 20, (world * Bb,), generator=gb).to(dev)
+    torch.manual_seed(3)
+    big = sparch_amd.SNN((Bb, None, C), [1024, 1024, 20], neuron_type="RadLIF", dropout=0.0).to(dev).train()
+    for p in big.parameters():
+        dist.broadcast(p.data, src=0)
+    state = {k: v.clone() for k, v in big.state_dict().items()}
+    red = dp.GradAllReducer(big, policy="overlap", rows_per_rank=Bb)
+    got, tries = None, 0
+    for tries in range(1, 4):
+        big.load_state_dict(state)
+        _, got = grads_of(big, dp.shard_batch(xb, rank, world), dp.shard_batch(yb, rank, world), 300 + rank, red,
+                          check=False)
+        if not Fn.poll_status(dev):  # (finish() made the word collective: both ranks take the same branch)
+            break
+        print(f"rank {rank}: forced overlap on a full grid, attempt {tries}: {Fn.describe_timeout()} -> "
+              f"per-step launches on every rank", flush=True)
+        Fn.degrade(dev)
+    else:
+        raise AssertionError("the step still times out after degrading to per-step launches")
+    red.remove()
+    shard_b = []
+    for r in range(world):
+        big.load_state_dict(state)
+        shard_b.append(grads_of(big, dp.shard_batch(xb, r, world), dp.shard_batch(yb, r, world), 300 + r)[1])
+    for k in got:
+        e = relmax(got[k], (shard_b[0][k] + shard_b[1][k]) / 2)
+        assert e <= 2e-6, ("forced overlap", k, e)
+    print(f"rank {rank}: forced overlap on a full grid finished after {tries} attempt(s), gradients correct "
+          f"(per-step launches: {bool(Fn._degraded)})", flush=True)
+    Fn._degraded.clear()
+    del big, red, shard_b, got
+
+    # ---- 1c. a timeout on ONE rank: rank 1's status word is raised by hand between backward and the reducer.  The
+    #          reducer makes the word collective, so BOTH ranks' optimizer steps are no-ops on the device (the peers
+    #          had averaged rank 1's invalid gradients in), both count the skipped step, both take it back from
+    #          Adam's bias-correction counter when they read the word — and the replicas stay identical.
+    torch.manual_seed(4)
+    net = sparch_amd.SNN((B // world, None, C), [64, 64, 20], neuron_type="RadLIF", dropout=0.0).to(dev).train()
+    for p in net.parameters():
+        dist.broadcast(p.data, src=0)
+    opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)
+    red = dp.GradAllReducer(net, rows_per_rank=B // world)
+
+    def train_step(seed, poison):
+        opt.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        out, _ = net(xs)
+        torch.nn.functional.cross_entropy(out, ys).backward()
+        if poison:
+            Fn.status_word(dev)[0] = 1
+        red.finish()
+        opt.step()
+
+    def replicas_equal():
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        return bool(torch.equal(both[0], both[1])), flat
+
+    train_step(500 + rank, False)
+    ok, before = replicas_equal()
+    assert ok and not Fn.poll_status(dev)
+    train_step(501 + rank, poison=(rank == 1))
+    ok, after = replicas_equal()
+    assert ok, "replicas diverged after a timeout on one rank"
+    assert torch.equal(before, after), "a step with a raised status word must not move the parameters on ANY rank"
+    assert Fn.poll_status(dev), f"rank {rank} did not see the peer's timeout"
+    assert Fn.last_timeout["skipped_steps"] == 1
+    steps = {float(opt.state[p]["step"]) for p in net.parameters()}
+    assert steps == {1.0}, steps  # the skipped step was taken back from the bias-correction counter
+    train_step(502 + rank, False)
+    ok, later = replicas_equal()
+    assert ok and not torch.equal(later, after) and not Fn.poll_status(dev)
+    red.remove()
+    print(f"rank {rank}: a timeout on one rank skips the step on both; replicas identical", flush=True)
 
     # ---- 2. SyncBN: two ranks x B/2 rows == one process x B rows
     torch.manual_seed(2)
