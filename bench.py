@@ -229,7 +229,7 @@ def main():
     net.train()
     state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}  # for the CPU baseline leg
     opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)  # exp.py:89 (same arithmetic, one launch: SURVEY f-2)
-    loss_fn = torch.nn.CrossEntropyLoss()           # exp.py:100
+    loss_fn = Fn.CrossEntropyLoss()                 # exp.py:100 (one launch for the loss and its gradient)
     reducer = dp.GradAllReducer(net, rows_per_rank=B) if world > 1 else None
     if world > 1 and args.sync_bn:
         Fn.SYNC_BN = {"group": None, "world": world}

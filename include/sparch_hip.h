@@ -541,6 +541,13 @@ int sparch_adam_step(int n_tensors, float* const* params, const float* const* gr
                      float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                      void* stream);
 
+/* ---- a11: the train step's loss (exp.py:100, 362: nn.CrossEntropyLoss()(output, y), mean over the batch) and its
+ * gradient with respect to the logits, one launch: loss[0] = mean_b(logsumexp(x_b) - x_b[y_b]),
+ * dlogits = (softmax(x) - onehot(y)) / B.  logits (B,C) fp32, labels (B) int64 (a label outside [0,C) contributes
+ * nothing), loss (1) fp32, dlogits (B,C) fp32. */
+int sparch_ce_loss(int B, int C, const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,51 @@ extern "C" int sparch_softmax_sum_bwd(int B, int T, int K, const float* x, const
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
+
+// ---- a11: the loss of the train step, nn.CrossEntropyLoss()(output, y) (exp.py:100, 362; mean reduction), and its
+//      gradient with respect to the logits in ONE launch: eager torch spends seven small kernels on it per step
+//      (cat, log-softmax, nll forward, two fills, nll backward, log-softmax backward).  One workgroup; a thread
+//      owns batch rows b, b + 256, ...: max, sum of exponentials, loss_b = log(sum) + max - x[label] and
+//      dlogits = (softmax - onehot) / B; the B row losses are summed in a fixed order (deterministic).
+namespace {
+__global__ __launch_bounds__(256) void ce_loss_kernel(int B, int C, const float* __restrict__ x,
+                                                      const long long* __restrict__ y, float* __restrict__ loss,
+                                                      float* __restrict__ dx) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x;
+    const float inv_b = 1.0f / (float)B;
+    float acc = 0.0f;
+    for (int b = tid; b < B; b += 256) {
+        const float* row = x + (size_t)b * C;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        const float lse = logf(s);
+        const int lab = (int)y[b];
+        const bool lab_ok = lab >= 0 && lab < C;
+        if (lab_ok) acc += (lse + m) - row[lab];
+        for (int c = 0; c < C; ++c) {
+            const float p = expf((row[c] - m) - lse);  // softmax through log-softmax, as torch's backward does
+            dx[(size_t)b * C + c] = (p - ((lab_ok && c == lab) ? 1.0f : 0.0f)) * inv_b;
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) part[tid] += part[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = part[0] * inv_b;
+}
+}  // namespace
+
+extern "C" int sparch_ce_loss(int B, int C, const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                              void* stream) {
+    SPARCH_ENTER();
+    if (B <= 0 || C <= 0 || !logits || !labels || !loss || !dlogits) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, C, logits,
+                       reinterpret_cast<const long long*>(labels), loss, dlogits);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}

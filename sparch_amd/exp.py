@@ -114,7 +114,7 @@ class Experiment:
         self.opt = optim.Adam(self.net.parameters(), self.lr)  # exp.py:89, one launch per step (f-2)
         self.scheduler = ReduceLROnPlateau(optimizer=self.opt, mode="max", factor=self.scheduler_factor,
                                            patience=self.scheduler_patience, min_lr=1e-6)
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = Fn.CrossEntropyLoss()  # exp.py:100 (one launch for the loss and its gradient)
         self.reducer = None
         if self.world > 1:
             self.reducer = dp.GradAllReducer(self.net, rows_per_rank=self.batch_size // self.world)

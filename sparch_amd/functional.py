@@ -523,10 +523,17 @@ class _Norm:
 
 
 # ----------------------------------------------------------------------------- cells (given Wx)
+_placeholder_zero = {}  # one element per device (a fresh torch.zeros(1) per layer and step was a fill kernel each)
+
+
 def spike_placeholder(B, T, F, device):
     """(B,T,F) fp32 stand-in for a spike tensor whose only consumer reads its bf16 plane: one element of storage,
     expanded — autograd needs the edge's shape and dtype, nobody reads the values."""
-    return torch.zeros(1, dtype=torch.float32, device=device).expand(B, T, F)
+    key = str(device)
+    z = _placeholder_zero.get(key)
+    if z is None:
+        z = _placeholder_zero[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z.expand(B, T, F)
 
 
 def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_drop, seed, steps_per_launch=None,
@@ -948,6 +955,42 @@ class ReadoutCellFn(torch.autograd.Function):
                                      ptr(u0), ptr(dWx), ptr(ws), _stream()), "sparch_readout_bwd")
         (dalpha,) = _finish_param_grads(ws, B, C, [alpha], [ALPHA_LIM])
         return dWx, dalpha, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(output, y) of the train step (exp.py:100, 362; mean reduction) with its gradient, in
+    one launch (`sparch_ce_loss`): eager torch runs seven small kernels for it per step."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _require_device(logits, "logits")
+        logits = _f32c(logits)
+        B, C = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        check(lib.sparch_ce_loss(B, C, ptr(logits), ptr(labels.contiguous()), ptr(loss), ptr(dlogits), _stream()),
+              "sparch_ce_loss")
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+def cross_entropy(logits, labels):
+    """Mean cross-entropy of (B,C) logits against int64 class labels on the device (see CrossEntropyFn)."""
+    if labels.dtype != torch.int64 or logits.ndim != 2:
+        return torch.nn.functional.cross_entropy(logits, labels)
+    return CrossEntropyFn.apply(logits, labels)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for the reference's `nn.CrossEntropyLoss()` (exp.py:100) on the HIP path."""
+
+    def forward(self, output, target):
+        return cross_entropy(output, target)
 
 
 def fbank(wave, num_mel_bins=40):

@@ -1504,6 +1504,25 @@ def test_full_size_properties(sp, neuron_type, sizes, B, T, C):
 
 # ------------------------------------------------------------------ f-2: optimizer step on the device
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,C", [(1, 2), (37, 35), (256, 35), (700, 256), (300, 20)])
+def test_cross_entropy_kernel_vs_torch(B, C):
+    """The train step's loss (exp.py:100, 362: nn.CrossEntropyLoss(), mean over the batch) and its gradient in one
+    launch (sparch_ce_loss) against torch's own cross_entropy on the CPU: loss to 2e-6 relative, d loss / d logits
+    to 1e-7 absolute (entries are <= 1 / B), also under an upstream factor (the regulariser adds to the loss)."""
+    Fn = _Fn()
+    g = torch.Generator().manual_seed(B + C)
+    x = (torch.randn(B, C, generator=g) * 3.0).requires_grad_(True)
+    y = torch.randint(0, C, (B,), generator=g)
+    ref = torch.nn.functional.cross_entropy(x, y)
+    (ref * 1.5).backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = Fn.CrossEntropyLoss()(xd, y.to(DEV))
+    (got * 1.5).backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((xd.grad.cpu() - x.grad).abs().max()) <= 1e-7 * 1.5 + 1e-6 * float(x.grad.abs().max())
+
+
+@pytest.mark.gpu
 def test_adam_step_matches_torch_adam():
     """sparch_amd.optim.Adam vs torch.optim.Adam on the CPU (the reference's optimizer, exp.py:89) on the same
     gradients: same operation order; the host's vectorised kernels contract some multiply-adds and its
