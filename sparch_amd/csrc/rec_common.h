@@ -15,7 +15,8 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr int RT = 32;       // rows per batch tile
 constexpr int CT = 32;       // columns per workgroup (= one k-group of its consumers)
-constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles
+constexpr int RED_LD = 33;   // padded row of the cross-wave reduction tiles (read with 4-byte accesses)
+constexpr int RED_LD4 = 32;  // ... of the spiking cells' tiles, read with one 16-byte access per partial tile
 #ifndef REC_RING
 #define REC_RING 4
 #endif
@@ -46,6 +47,9 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #endif
 #ifndef REC_FWD_UPPER_SLEEP
 #define REC_FWD_UPPER_SLEEP 0  /* forward: s_sleep units (64 cycles) of the waves without pointwise state before they poll again */
+#endif
+#ifndef REC_BWD_UPPER_RESET
+#define REC_BWD_UPPER_RESET 1  /* backward: the ring's sentinels are put back by the waves without pointwise state */
 #endif
 #ifndef REC_BWD_PARK
 #define REC_BWD_PARK 0  /* backward: the step's saved states wait in LDS instead of VGPRs (see reccell.hip; measured 1.056 vs 1.043 ms per launch, and a second k-group of tile loads in flight still spills: off) */

@@ -95,8 +95,8 @@ struct RecArgs {
 // Diagnostic build only (-DSPARCH_REC_PROF, never shipped): per-workgroup sums of s_memtime
 // deltas for the segments of a time step, written to a private buffer no kernel reads.
 #ifdef SPARCH_REC_PROF
-__device__ u64 g_rec_prof[2][512][8];
-#define PROF_DECL u64 pf_t = 0, pf_acc[6] = {0, 0, 0, 0, 0, 0};
+__device__ u64 g_rec_prof[2][512][12];
+#define PROF_DECL u64 pf_t = 0, pf_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_STAMP(i)                                                                           \
     do {                                                                                        \
         u64 now_;                                                                               \
@@ -108,7 +108,7 @@ __device__ u64 g_rec_prof[2][512][8];
     } while (0)
 #define PROF_FLUSH(which)                                                                       \
     if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 256)  /* wave 0, and wave 4 in slots 256.. */ \
-        for (int i_ = 0; i_ < 6; ++i_) g_rec_prof[which][blockIdx.x + (threadIdx.x ? 256 : 0)][i_] += pf_acc[i_];
+        for (int i_ = 0; i_ < 10; ++i_) g_rec_prof[which][blockIdx.x + (threadIdx.x ? 256 : 0)][i_] += pf_acc[i_];
 #else
 #define PROF_DECL
 #define PROF_STAMP(i)
@@ -122,7 +122,7 @@ __device__ u64 g_rec_prof[2][512][8];
 // NP: planes of V — 3 = exact split (default), 1 = the bf16 operand mode (V rounded once by the pack kernel).
 template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3>
 __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD];
+    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD4];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
     __shared__ int abort_flag[2];
     __shared__ int xcd_local_flag;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                rd[row * RED_LD + li] = acc[i];
+                rd[row * RED_LD4 + li] = acc[i];
             }
             PROF_STAMP(1);  // expand + MFMA + LDS write
         }
@@ -366,18 +366,22 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
         if (t > 0 && !EXT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rec[e] = red[t & 1][0][r * RED_LD + cq * 4 + e];
+            for (int e = 0; e < 4; ++e) rec[e] = red[t & 1][0][r * RED_LD4 + cq * 4 + e];
         }
 #else
         if (t > 0 && !EXT) {
+            // unpadded 128-byte rows: a thread's four columns are one aligned ds_read_b128 per partial tile, and the
+            // b128 lane groups (rows r, r+1 of column quads 0-3 / 4-7) fall on all 64 banks (conflict-free, like the
+            // MFMA lanes' ds_write_b32 of 32 consecutive floats) — 8 LDS instructions instead of 32 on this chain
+            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[t & 1][0][r * RED_LD4 + cq * 4]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = r * RED_LD + cq * 4 + e;
-                float sum = red[t & 1][0][o];
+            for (int w_ = 1; w_ < NW; ++w_) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[t & 1][w_][r * RED_LD4 + cq * 4]);
 #pragma unroll
-                for (int w_ = 1; w_ < NW; ++w_) sum = sum + red[t & 1][w_][o];
-                rec[e] = sum;
+                for (int e = 0; e < 4; ++e) sum[e] = sum[e] + v[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rec[e] = sum[e];
         }
 #endif
 
@@ -501,7 +505,7 @@ template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3, bool S16 = 
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
     // waves, which reach the second (publish) barrier only when done with them -> one buffer
-    __shared__ __attribute__((aligned(16))) float red[NW][RT * RED_LD];
+    __shared__ __attribute__((aligned(16))) float red[NW][RT * RED_LD4];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NP == 3 ? NW : 1][NP == 3 ? KGW : 1][2][64];
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                rd[row * RED_LD + li] = acc[i];
+                rd[row * RED_LD4 + li] = acc[i];
             }
             PROF_STAMP(1);  // per k-group: wait, split, MFMA; LDS write
         }
@@ -827,6 +831,28 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #if REC_BWD_LATE_PREFETCH == 2
         if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
 #endif
+#ifndef REC_NO_RESET
+        if (BXS && REC_BWD_UPPER_RESET && !pw) {
+            // The sentinels go back into this workgroup's tile of step t+2 (every peer has consumed it: see the
+            // header) from the waves WITHOUT pointwise state, which idle from here to the publish barrier — as
+            // 16-byte stores, one or two per thread, instead of three 8-byte stores per pointwise thread between
+            // the publish stores and the publish barrier, i.e. on the step's critical chain (round 3).  These
+            // waves' `vm_settled()` behind the next reduction barrier retires them two barriers before the slot
+            // is written again (the publish of step t-2).
+            const u32x4 sent4 = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+            const unsigned so = (unsigned)((t + 2) % RING) * slot_bytes + rt_off + (unsigned)ct * PT;
+            constexpr int PIECES = NP * 128;  // 16-byte pieces of one tile
+#pragma unroll
+            for (int q = 0; q < (PIECES + 255) / 256; ++q) {
+                const int piece = (tid - 256) + 256 * q;
+                // (nothing to reset: an offset beyond the buffer resource — chosen per piece, a base of 0xFFFFF000
+                // plus 16 * piece would wrap around into the ring's first tile)
+                const unsigned o = (t + 2 < T && piece < PIECES) ? so + (unsigned)piece * 16u : 0xFFFFF000u;
+                if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(sent4, rsrc, o, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(sent4, rsrc, o, 0, REC_ST_AUX);
+            }
+        }
+#endif
         if (BXS && valid_hi && t + 1 < a.t_end) {  // the previous step's staged outputs -> HBM (upper waves)
             const int t1 = t + 1, tt1 = d ? (T - 1 - t1) : t1;
             st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
@@ -837,6 +863,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         // took vector issue slots and LDS cycles from the pointwise waves they share a SIMD with).
         float sp[4] = {0.f, 0.f, 0.f, 0.f}, du_new[4] = {0.f, 0.f, 0.f, 0.f}, dw_new[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 dwx = {0.f, 0.f, 0.f, 0.f}, spv = dwx;
+        PROF_STAMP(6);  // behind the barrier: settle, flag read, prefetch issue, staged stores
         f32x4 up_use = upv, ut_use = {u_t[0], u_t[1], u_t[2], u_t[3]};
         if (PARK && pw) { up_use = park_u[t & 1][pt]; ut_use = park_u[(t + 1) & 1][pt]; }
         if (pw_wave) {
@@ -844,16 +871,18 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
         } else if (t + 1 < T) {
+            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[0][r * RED_LD4 + cq * 4]);  // (see the forward)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = r * RED_LD + cq * 4 + e;
-                float sum = red[0][o];
+            for (int w = 1; w < NW; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][r * RED_LD4 + cq * 4]);
 #pragma unroll
-                for (int w = 1; w < NW; ++w) sum = sum + red[w][o];
-                rec[e] = sum;
+                for (int e = 0; e < 4; ++e) sum[e] = sum[e] + v[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rec[e] = sum[e];
         }
 
+        PROF_STAMP(7);  // partial-tile reduction
         // ---- pointwise reverse step (its rec-independent part: pre_pointwise above)
         if (t > 0) {
 #pragma unroll
@@ -874,6 +903,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             dw_new[e] = ADAPT ? be[e] * dw_n[e] - dwx[e] : 0.f;
             spv[e] = (t > 0) ? sp[e] : 0.0f;  // binary rows only: the s0 term of dV is added by the host
         }
+        PROF_STAMP(8);  // reverse-step arithmetic
         // ---- publish dWx_t first: this thread's 4 values are one 16-byte piece of the tile in fragment
         //      order (columns cq*4.. -> k16-step ks = cq>>2, k-half h = (cq>>1)&1, quad q = cq&1), one
         //      write-through store; then the sentinel goes back into the slot of step t+2 (see header)
@@ -915,7 +945,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 }
             }
 #ifndef REC_NO_RESET
-            {
+            if (!(BXS && REC_BWD_UPPER_RESET)) {  // (8-wave kernels: the upper waves put the sentinels back, see below)
                 const u32x2 sent = {SENTINEL, SENTINEL};
                 const unsigned so = t + 2 < T ? (unsigned)((t + 2) % RING) * slot_bytes + tile_off : 0xFFFFF000u;
 #pragma unroll
@@ -1535,7 +1565,7 @@ bool al16(std::initializer_list<const void*> ps) {
 
 #ifdef SPARCH_REC_PROF
 extern "C" int sparch_rec_prof_read(unsigned long long* host_out, int reset) {
-    static unsigned long long zero[2 * 512 * 8];
+    static unsigned long long zero[2 * 512 * 12];
     if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rec_prof), sizeof(zero)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_rec_prof), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;

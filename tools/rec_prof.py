@@ -25,7 +25,7 @@ u0, w0, s0 = (torch.rand(B, H, generator=g).to(dev) for _ in range(3))
 gs = torch.randn(B, T, H, generator=g).to(dev)
 lib = _capi.lib
 lib.sparch_rec_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros((2, 512, 8), np.uint64)
+buf = np.zeros((2, 512, 12), np.uint64)
 
 
 def run():
@@ -44,12 +44,13 @@ e1.record()
 torch.cuda.synchronize()
 lib.sparch_rec_prof_read(buf.ctypes.data, 1)
 print(f"fwd+bwd wall {e0.elapsed_time(e1):.3f} ms, firing rate {float(s.mean()):.4f}")
-names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-"],
-         ["first load issue", "wait+split+mfma+lds", "barrier", "pointwise+publish", "publish barrier", "stores+partial sums"]]
+names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-", "-", "-", "-", "-"],
+         ["first load issue", "wait+split+mfma+lds", "barrier", "split+publish stores", "publish barrier", "stores+partial sums",
+          "settle+prefetch issue", "tile reduction", "reverse-step arithmetic", "-"]]
 for w, label in [(0, "forward"), (1, "backward"), (2, "forward, wave 4"), (3, "backward, wave 4")]:
-    a = buf[w % 2, 256 * (w // 2):256 * (w // 2) + 256, :6].astype(np.float64) / T
+    a = buf[w % 2, 256 * (w // 2):256 * (w // 2) + 256, :10].astype(np.float64) / T
     w = w % 2
     print(f"{label}: cycles per step (mean over workgroups | min | max)")
-    for i in range(6):
+    for i in range(10):
         print(f"   {names[w][i]:20s} {a[:, i].mean():9.0f} | {a[:, i].min():9.0f} | {a[:, i].max():9.0f}")
     print(f"   {'sum':20s} {a.sum(1).mean():9.0f}  (= {a.sum(1).mean() / 100:.2f} us at 100 MHz s_memtime? see note)")
