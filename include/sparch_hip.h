@@ -541,6 +541,15 @@ int sparch_adam_step(int n_tensors, float* const* params, const float* const* gr
                      float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                      void* stream);
 
+/* ---- a11: the batch upload of the train step (exp.py:355-356 copies a dense fp32 batch to the device every step:
+ * 179 MB at the headline shape).  counts (M,K) uint8 = the same binned spike counts (spiking_datasets.py:71-78) at
+ * one byte per element; the call expands them into the bf16 plane the first layer's GEMMs read — (M, ldp) uint16
+ * bit patterns, ldp >= K a multiple of 8, zeros behind column K: the layout and the values of
+ * sparch_plane_bf16_exact on the float batch, whose flag would read 1 — and, if x != NULL, into the fp32 tensor
+ * (M rows of ldx floats). */
+int sparch_expand_counts_u8(long long M, int K, const uint8_t* counts, uint16_t* plane, int ldp, float* x, int ldx,
+                            void* stream);
+
 /* ---- a11: the train step's loss (exp.py:100, 362: nn.CrossEntropyLoss()(output, y), mean over the batch) and its
  * gradient with respect to the logits, one launch: loss[0] = mean_b(logsumexp(x_b) - x_b[y_b]),
  * dlogits = (softmax(x) - onehot(y)) / B.  logits (B,C) fp32, labels (B) int64 (a label outside [0,C) contributes

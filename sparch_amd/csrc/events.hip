@@ -41,7 +41,39 @@ __global__ void bin_events_kernel(long long n_events, const float* __restrict__ 
     atomicAdd(out + ((size_t)lo * nb_steps + bin) * nb_units + u, 1.0f);
 }
 
+// ---- a11 (exp.py:355-356): a batch of binned spike counts uploaded as ONE BYTE per element and expanded on the
+// device.  The reference copies the dense float batch over PCIe every step ((256, 250, 700) fp32 = 179 MB against
+// 45 MB as uint8); counts are small non-negative integers (spiking_datasets.py:71-78), exact in uint8 up to 255
+// and in bf16 up to 256.  One pass writes the bf16 plane the first layer's GEMMs read (rows padded to ldp
+// elements, zeros behind column K — the layout of sparch_plane_bf16_exact) and, on request, the fp32 tensor.
+__global__ __launch_bounds__(256) void expand_counts_kernel(long long M, int K, const uint8_t* __restrict__ c,
+                                                            uint16_t* __restrict__ plane, int ldp,
+                                                            float* __restrict__ x, int ldx) {
+    const long long n = M * (long long)ldp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / ldp;
+        const int k = (int)(i - m * ldp);
+        const unsigned v = k < K ? (unsigned)c[m * K + k] : 0u;
+        const float f = (float)v;                       // <= 255: exact in bf16 (8 significant bits)
+        plane[i] = (uint16_t)(__float_as_uint(f) >> 16);
+        if (x && k < K) x[m * ldx + k] = f;
+    }
+}
+
 }  // namespace
+
+extern "C" int sparch_expand_counts_u8(long long M, int K, const uint8_t* counts, uint16_t* plane, int ldp,
+                                       float* x, int ldx, void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || K <= 0 || !counts || !plane || ldp < K || (ldp % 8) != 0 || (x && ldx < K)) return SPARCH_EINVAL;
+    if (!aligned16(plane)) return SPARCH_EALIGN;
+    const long long n = M * (long long)ldp;
+    const unsigned grid = (unsigned)((n + 256 * 8 - 1) / (256 * 8) < 65535 * 16 ? (n + 256 * 8 - 1) / (256 * 8) : 65535 * 16);
+    hipLaunchKernelGGL(expand_counts_kernel, dim3(grid ? grid : 1), dim3(256), 0, (hipStream_t)stream, M, K, counts,
+                       plane, ldp, x, ldx);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
 
 extern "C" int sparch_bin_events(long long n_events, const float* times, const int* units,
                                  const long long* sample_offsets, int n_samples, int nb_steps, int nb_units,

@@ -291,6 +291,42 @@ def plane_bf16_exact(x2):
     return plane, flag
 
 
+_flag_one = {}
+
+
+def input_from_counts(counts):
+    """A batch of binned spike counts as (B,T,K) uint8 ON THE DEVICE -> the network input for SNN.forward: a
+    (B,T,K) fp32 PLACEHOLDER (no values are written) carrying the bf16 plane the first layer's GEMMs read, made by
+    one pass over the bytes (`sparch_expand_counts_u8`).  The reference uploads the dense float batch every step
+    (exp.py:355-356: 179 MB at the headline shape against 45 MB of bytes); counts up to 255 are exact in both
+    uint8 and bf16, so the plane — and everything computed from it — is the one `plane_bf16_exact` makes from the
+    float batch."""
+    _require_device(counts, "counts")
+    if counts.dtype != torch.uint8 or counts.ndim != 3:
+        raise ValueError("input_from_counts: a (B,T,K) uint8 tensor of spike counts")
+    counts = counts.contiguous()
+    B, T, K = counts.shape
+    M, ldp = B * T, (K + 7) // 8 * 8
+    plane = torch.empty(M, ldp, dtype=torch.bfloat16, device=counts.device)
+    check(lib.sparch_expand_counts_u8(M, K, ptr(counts), ptr(plane), ldp, None, 0, _stream()), "sparch_expand_counts_u8")
+    key = str(counts.device)
+    one = _flag_one.get(key)
+    if one is None:
+        one = _flag_one[key] = torch.ones(4, dtype=torch.int32, device=counts.device)
+    x = spike_placeholder(B, T, K, counts.device)
+    x = x.view(B, T, K)  # a tensor object of its own for the tag (same one-element storage)
+    x._sparch_input_plane = (tuple(x.shape), plane, one)
+    return x
+
+
+def input_plane_of(x):
+    """(plane, flag) if x is an input made by `input_from_counts`, else None."""
+    tag = getattr(x, "_sparch_input_plane", None)
+    if tag is None or tag[0] != tuple(x.shape):
+        return None
+    return tag[1], tag[2]
+
+
 def split_planes(W):
     """The three exact bf16 planes of a weight matrix, (3, *W.shape) bf16 (W = p0 + p1 + p2 exactly, the
     truncation split the GEMM kernels otherwise redo in every workgroup that stages a tile of W); None where
@@ -329,7 +365,7 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None,
                                        ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
     elif a_exact_flag is not None and a_plane is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
         tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")  # a_plane: plane_bf16_exact(A)[0], read when the flag is 1
-        check(lib.sparch_gemm_auto16_nt(M, N, K, ptr(A), A.stride(0), ptr(a_plane), a_plane.stride(0), ptr(B),
+        check(lib.sparch_gemm_auto16_nt(M, N, K, ptr(A), A.stride(0) or K, ptr(a_plane), a_plane.stride(0), ptr(B),
                                         B.stride(0), ptr(C), N, ptr(bias), ptr(ws), ptr(a_exact_flag), _stream()),
               "sparch_gemm_auto16_nt")
     elif a_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
@@ -391,7 +427,7 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b
         nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, (N + 7) // 8 * 8, K)  # slabs at the plane's padded width
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
-        check(lib.sparch_gemm_auto16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(b_plane),
+        check(lib.sparch_gemm_auto16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0) or N, ptr(b_plane),
                                         b_plane.stride(0), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
                                         ptr(b_exact_flag), ptr(ws), nbytes, _stream()), "sparch_gemm_auto16_tn")
     elif b_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
@@ -733,7 +769,8 @@ class SpikingLayerFn(torch.autograd.Function):
         kind, norm, dirs = cfg["kind"], cfg["normalization"], cfg["dirs"]
         training, theta, p_drop, seed = cfg["training"], cfg["theta"], cfg["p_drop"], cfg["seed"]
         in_scale = cfg.get("in_spike_scale")  # input is a spike train of ours: entries 0 or in_scale
-        plane_in = in_scale is not None and cfg.get("in_spike16") is not None and USE_SPIKE_GEMM and USE_SPIKE16
+        plane_in = ((in_scale is not None and cfg.get("in_spike16") is not None and USE_SPIKE_GEMM and USE_SPIKE16)
+                    or cfg.get("in_plane") is not None)
         if not plane_in:  # (an input read through its bf16 plane may be a placeholder: never touch its values)
             x = _f32c(x)
         B, T, K = x.shape
@@ -743,7 +780,9 @@ class SpikingLayerFn(torch.autograd.Function):
         use_bn_stats = norm == "batchnorm" and training
         # otherwise (network input): let the device decide whether x is bf16-exact (binned spike counts are)
         xplane = None
-        if in_scale is None and USE_SPIKE_GEMM and USE_SPIKE16 and USE_INPUT_PLANE and DENSE_GEMM == "split6":
+        if cfg.get("in_plane") is not None:
+            xplane, xflag = cfg["in_plane"]  # the input came as bytes (input_from_counts): plane made, flag = 1
+        elif in_scale is None and USE_SPIKE_GEMM and USE_SPIKE16 and USE_INPUT_PLANE and DENSE_GEMM == "split6":
             xplane, xflag = plane_bf16_exact(x2)  # one pass: the flag AND the plane the two GEMMs read when it is 1
         else:
             xflag = flag_bf16_exact(x2) if (in_scale is None and USE_SPIKE_GEMM) else None

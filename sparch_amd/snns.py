@@ -360,6 +360,8 @@ class _SpikingLayer(nn.Module):
             "in_spike16": in_s16,  # the same spikes as a bf16 plane
             "states_ready": states_ready,
             "fp32_out": bool(fp32_out),
+            # network input uploaded as bytes (functional.input_from_counts): its bf16 plane and the flag "exact"
+            "in_plane": Fn.input_plane_of(x) if in_scale is None else None,
             # BatchNorm1d's counter: advanced by the statistics kernel (no separate launch; not on skipped steps)
             "num_batches_tracked": self.norm.num_batches_tracked if (is_bn and self.training) else None,
         }

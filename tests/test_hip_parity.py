@@ -1504,6 +1504,42 @@ def test_full_size_properties(sp, neuron_type, sizes, B, T, C):
 
 # ------------------------------------------------------------------ f-2: optimizer step on the device
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,K", [("RadLIF", 700), ("adLIF", 40), ("LIF", 33)])
+def test_input_uploaded_as_bytes_equals_the_float_batch(sp, kind, K):
+    """The train step's batch as one byte per element (functional.input_from_counts; the reference moves the dense
+    float batch over PCIe every step, exp.py:355-356): counts 0..6 — more than one spike per bin included — must
+    give, bit for bit, the plane `plane_bf16_exact` makes from the float batch (flag 1), and the network fed the
+    bytes the same output, firing rates and parameter gradients as the network fed the floats."""
+    Fn = _Fn()
+    B, T = 6, 25
+    g = torch.Generator().manual_seed(K)
+    counts = torch.poisson(torch.full((B, T, K), 0.3), generator=g).clamp_(max=6).to(torch.uint8)
+    assert int(counts.max()) > 1
+    xf = counts.float().to(DEV)
+    xb = Fn.input_from_counts(counts.to(DEV))
+    plane_ref, flag_ref = Fn.plane_bf16_exact(xf.view(B * T, K))
+    plane, flag = Fn.input_plane_of(xb)
+    assert int(flag_ref[0]) == 1 and int(flag[0]) == 1
+    assert tuple(plane.shape) == tuple(plane_ref.shape)
+    assert torch.equal(plane.view(torch.int16), plane_ref.view(torch.int16))
+    torch.manual_seed(2)
+    net = sp.SNN((B, None, K), [64, 48, 10], neuron_type=kind, dropout=0.0).to(DEV).train()
+    y = torch.randint(0, 10, (B,), generator=g).to(DEV)
+    res = []
+    for x in (xf, xb):
+        net.zero_grad()
+        torch.manual_seed(5)
+        out, rates = net(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        Fn.check_status()
+        res.append((out.detach().clone(), rates.detach().clone(), {k: v.grad.clone() for k, v in net.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert kind == "LIF" or float(res[0][1].sum()) > 0  # (the small LIF net stays silent on this input)
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C", [(1, 2), (37, 35), (256, 35), (700, 256), (300, 20)])
 def test_cross_entropy_kernel_vs_torch(B, C):
     """The train step's loss (exp.py:100, 362: nn.CrossEntropyLoss(), mean over the batch) and its gradient in one
