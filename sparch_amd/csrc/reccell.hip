@@ -120,34 +120,46 @@ __device__ u64 g_rec_prof[2][512][12];
 // summed through LDS); NW = 8 puts two waves on each SIMD so that one's LUT reads / poll latency sit
 // under the other's MFMAs.  Pointwise update, publish and stores stay on the first 256 threads.
 // NP: planes of V — 3 = exact split (default), 1 = the bf16 operand mode (V rounded once by the pack kernel).
-template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3>
+// CW (round 3): 32-column groups per workgroup.  1: a workgroup owns 32 columns and its first 256 threads the
+// pointwise state (above).  2 (bf16 operand mode, 8 waves): it owns 64 columns — with ONE plane of V the slice is
+// 128 KiB, a quarter of the register file — and all 512 threads own pointwise state (thread = (column group j,
+// row, column quad)); a batch of 512 virtual rows (a bidirectional B = 256 layer, BASELINE configs[4]) is then
+// 16 row tiles x 16 workgroups = ONE persistent launch on 256 CUs instead of two half-filled ones run back to
+// back.  The hand-off format does not change: the workgroup publishes the granules of k-groups 2 ctw and
+// 2 ctw + 1, consumers read k-groups as before.
+template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3, int CW = 1>
 __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][NW][RT * RED_LD4];
+    static_assert(CW == 1 || (CW == 2 && NW == 8 && !EXT), "64-column workgroups: the 8-wave persistent kernels");
+    __shared__ __attribute__((aligned(16))) float red[2][NW][CW][RT * RED_LD4];
     __shared__ __attribute__((aligned(16))) u32x4 lut[256];  // byte of 8 spikes -> 8 bf16 (0 / 1.0)
     __shared__ int abort_flag[2];
     __shared__ int xcd_local_flag;
-    __shared__ unsigned cnt_lds[2][CT];
+    __shared__ unsigned cnt_lds[2][CW * CT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
     const int rt = a.rt_base + (int)(blockIdx.x % a.n_rt_launch);
-    const int ct = (int)(blockIdx.x / a.n_rt_launch);
+    const int ctw = (int)(blockIdx.x / a.n_rt_launch);  // the workgroup's index among its row tile's workgroups
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
 
-    // element ownership for the pointwise update: row r, 4 columns
-    const bool pw = tid < 256;
-    const bool pw_wave = NW == 4 || wave < 4;  // the same, as a scalar (wave-uniform branches)
+    // element ownership for the pointwise update: row r, 4 columns (of column group ct)
+    const bool pw = tid < 256 * CW;
+    const bool pw_wave = NW == 4 || CW == 2 || wave < 4;  // the same, as a scalar (wave-uniform branches)
+    const int ct = ctw * CW + (CW == 2 ? tid >> 8 : 0);   // this THREAD's 32-column group
     const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
     const bool valid = pw && bp < a.Bp && col < H;
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    u32x4 vb[KGW][2][NP];
-    if (!EXT) load_vslice<KGW, NW, NP>(vb, a.vpack, ct, a.nkg, wave, lane);
-    if (pw) {
+    u32x4 vb[CW][KGW][2][NP];
+    if (!EXT) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) load_vslice<KGW, NW, NP>(vb[c], a.vpack, ctw * CW + c, a.nkg, wave, lane);
+    }
+    if (tid < 256) {
         u32x4 e;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -183,9 +195,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         }
     }
     if (tid < 2) abort_flag[tid] = 0;
-    if (tid < 2 * CT) cnt_lds[tid / CT][tid % CT] = 0;
+    if (tid < 2 * CW * CT) cnt_lds[tid / (CW * CT)][tid % (CW * CT)] = 0;
     const unsigned my_xcc = xcc_id();
-    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, 0u, a.n_ct, ct, my_xcc, tid, &xcd_local_flag);
+    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, 0u, a.n_ct / CW, ctw, my_xcc, tid, &xcd_local_flag);
     __syncthreads();
     const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     // waves poll too, with LESS lead over their stores (a pointwise phase instead of a whole step), and the
     // matrix phase waits for its slowest wave: the timing ablation's 0.75 k cycles (no stores at all) cannot be
     // had by moving the stores between waves of the same workgroup.
-    constexpr bool XSTORE = REC_XSTORE && NW == 8 && !EXT;
+    constexpr bool XSTORE = REC_XSTORE && NW == 8 && !EXT && CW == 1;
     __shared__ __attribute__((aligned(16))) f32x4 stage[XSTORE ? 2 : 1][3][XSTORE ? 256 : 1];
     const bool valid_hi = !pw && bp < a.Bp && col < H;  // an upper-wave thread, same (row, columns) as tid - 256
     auto store_step = [&](int st_t, const f32x4& vs, const f32x4& vu, const f32x4& vw) {
@@ -329,26 +341,33 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #endif
                 }
             }
-            f32x16 acc;
+            f32x16 acc[CW];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int c = 0; c < CW; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int p = NP - 1; p >= 0; --p) {
-#if defined(SPARCH_REC_PROF) && defined(FA_NO_MFMA)  // timing ablation (wrong results): operands kept alive, no MFMA
-                        asm volatile("" ::"v"(af[kk][ks]), "v"(vb[kk][ks][p]));
-#else
-                        acc = mfma_bf16(af[kk][ks], vb[kk][ks][p], acc);
-#endif
-                    }
-            float* rd = red[t & 1][wave];
+                    for (int p = NP - 1; p >= 0; --p)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                rd[row * RED_LD4 + li] = acc[i];
+                        for (int c = 0; c < CW; ++c) {
+#if defined(SPARCH_REC_PROF) && defined(FA_NO_MFMA)  // timing ablation (wrong results): operands kept alive, no MFMA
+                            asm volatile("" ::"v"(af[kk][ks]), "v"(vb[c][kk][ks][p]));
+#else
+                            acc[c] = mfma_bf16(af[kk][ks], vb[c][kk][ks][p], acc[c]);
+#endif
+                        }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                float* rd = red[t & 1][wave][c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    rd[row * RED_LD4 + li] = acc[c][i];
+                }
             }
             PROF_STAMP(1);  // expand + MFMA + LDS write
         }
@@ -366,17 +385,18 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_RED)  // timing ablation (wrong results): one partial tile instead of NW
         if (t > 0 && !EXT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rec[e] = red[t & 1][0][r * RED_LD4 + cq * 4 + e];
+            for (int e = 0; e < 4; ++e) rec[e] = red[t & 1][0][CW == 2 ? tid >> 8 : 0][r * RED_LD4 + cq * 4 + e];
         }
 #else
         if (t > 0 && !EXT) {
             // unpadded 128-byte rows: a thread's four columns are one aligned ds_read_b128 per partial tile, and the
             // b128 lane groups (rows r, r+1 of column quads 0-3 / 4-7) fall on all 64 banks (conflict-free, like the
             // MFMA lanes' ds_write_b32 of 32 consecutive floats) — 8 LDS instructions instead of 32 on this chain
-            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[t & 1][0][r * RED_LD4 + cq * 4]);
+            const int cj = CW == 2 ? tid >> 8 : 0;
+            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[t & 1][0][cj][r * RED_LD4 + cq * 4]);
 #pragma unroll
             for (int w_ = 1; w_ < NW; ++w_) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[t & 1][w_][r * RED_LD4 + cq * 4]);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[t & 1][w_][cj][r * RED_LD4 + cq * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sum[e] = sum[e] + v[e];
             }
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             else __hip_atomic_store(slot, granule, __ATOMIC_RELAXED, REC_ST_SCOPE);
         }
 #if !REC_FWD_UPPER_SLEEP
-        if (NW == 8) lds_barrier();  // releases the upper waves into the next step's poll (see the else branch)
+        if (NW == 8 && CW == 1) lds_barrier();  // releases the upper waves into the next step's poll (see the else branch)
 #endif
         PROF_STAMP(3);  // pointwise + publish
         if (valid) {
@@ -480,13 +500,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         if (valid) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (cnt[e]) atomicAdd(&cnt_lds[d][cq * 4 + e], cnt[e]);
+                if (cnt[e]) atomicAdd(&cnt_lds[d][(CW == 2 ? (tid >> 8) * CT : 0) + cq * 4 + e], cnt[e]);
         }
         __syncthreads();
-        if (tid < 2 * CT) {
-            const int dd = tid / CT, c = tid % CT;
+        if (tid < 2 * CW * CT) {
+            const int dd = tid / (CW * CT), c = tid % (CW * CT);
             const unsigned v = cnt_lds[dd][c];
-            if (v && dd < a.dirs && ct * CT + c < H) atomicAdd(a.spike_count + (size_t)dd * H + ct * CT + c, v);
+            if (v && dd < a.dirs && ctw * CW * CT + c < H) atomicAdd(a.spike_count + (size_t)dd * H + ctw * CW * CT + c, v);
         }
     }
 }
@@ -501,28 +521,31 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 // mode: the producer rounds its dWx once, 2 KB tiles, ONE MFMA per k16-step.
 // S16: the saved states u / w are bf16 (common.h save_u16) — a template parameter so that every global load of the
 // time loop is ONE unconditional instruction (see `load_step`).
-template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3, bool S16 = false>
+// CW: 32-column groups per workgroup (see rec_fwd_kernel): 2 = the bf16 operand mode's 64-column workgroups, all 512
+// threads own pointwise state, the workgroup publishes the tiles of k-groups 2 ctw and 2 ctw + 1.
+template <bool ADAPT, int KGW, int NW, bool EXT = false, int NP = 3, bool S16 = false, int CW = 1>
 __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
+    static_assert(CW == 1 || (CW == 2 && NW == 8 && !EXT && NP == 1), "64-column workgroups: bf16 operand mode, 8 waves");
     // cross-wave reduction tiles: written before the step's first barrier, read after it by the pointwise
     // waves, which reach the second (publish) barrier only when done with them -> one buffer
-    __shared__ __attribute__((aligned(16))) float red[NW][RT * RED_LD4];
+    __shared__ __attribute__((aligned(16))) float red[NW][CW][RT * RED_LD4];
     // lo plane of the V^T slice lives in LDS (64 KiB at H=1024) so the register file holds the
     // hi/mid planes (128 VGPRs) plus all 32 in-flight fp32 dWx tile loads (128 VGPRs) without spilling
     __shared__ __attribute__((aligned(16))) u32x4 vlo[NP == 3 ? NW : 1][NP == 3 ? KGW : 1][2][64];
     // neuron constants (alpha, beta, a, b, rate gradient, BatchNorm mean / invstd) of the tile's 8 column quads,
     // per direction (the rate gradient depends on it): kept in LDS and re-read each step — the 8-wave kernel's
     // 256-register budget has no room to hold them.  (Rounds 1-2 kept a copy per THREAD: 28 KB for 1.8 KB of data.)
-    __shared__ __attribute__((aligned(16))) f32x4 pcol[7][2][8];
+    __shared__ __attribute__((aligned(16))) f32x4 pcol[7][2][8 * CW];
     // initial states of the tile (u0, w0, s0): read by cell step 0 only — from LDS, so that the loop body holds no
     // global load on one path only (hipcc's wait-count pass merges such paths with an `s_waitcnt vmcnt(0)`)
-    __shared__ __attribute__((aligned(16))) f32x4 first_tile[3][256];
+    __shared__ __attribute__((aligned(16))) f32x4 first_tile[3][256 * CW];
     // running parameter-gradient partial sums (alpha, beta, a, b) of the thread's 4 columns: touched once per
     // step, off the critical path -> LDS, so that the hot loop's registers do not spill
 #if REC_ACC_REGS
     f32x4 pacc_r[6] = {};         // the six accumulators in registers (the k-group pipeline freed the room)
 #define PACC(j, i) pacc_r[j]
 #else
-    __shared__ __attribute__((aligned(16))) f32x4 pacc[6][256];  // + BatchNorm's sum dWx, sum dWx*xhat
+    __shared__ __attribute__((aligned(16))) f32x4 pacc[6][256 * CW];  // + BatchNorm's sum dWx, sum dWx*xhat
 #define PACC(j, i) pacc[j][i]
 #endif
     __shared__ int abort_flag[2];
@@ -531,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // points that use them — the spike of s_{t-1} and the parameter sums behind the publish barrier, u_t in the next
     // step's box-car gate — instead of in 16 VGPRs across the whole tile phase (the registers a second k-group of
     // tile loads in flight needs)
-    constexpr bool PARK = REC_BWD_PARK && NW == 8;
+    constexpr bool PARK = REC_BWD_PARK && NW == 8 && CW == 1;
     __shared__ __attribute__((aligned(16))) f32x4 park_u[PARK ? 2 : 1][PARK ? 256 : 1];
     __shared__ __attribute__((aligned(16))) f32x4 park_wx[PARK ? 2 : 1][PARK ? 256 : 1];
     // BXS (8-wave kernels): the step's bulk HBM stores (dWx for the GEMMs, the bf16 plane of s_{t-1}) are issued
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     // cycles ahead of their own next tile loads.  On the pointwise waves the stores sat ~0.8 k cycles in front of
     // the next step's tile loads, and `vmcnt` (in order, counts stores) made the first k-group wait for their
     // acknowledgement: timing ablation without the stores 1.29 -> 1.16 ms per launch.
-    constexpr bool BXS = REC_BWD_XSTORE && NW == 8 && !EXT;
+    constexpr bool BXS = REC_BWD_XSTORE && NW == 8 && !EXT && CW == 1;
     __shared__ __attribute__((aligned(16))) f32x4 stage_dwx[BXS ? 256 : 1];
     __shared__ __attribute__((aligned(8))) u32x2 stage_sp[BXS ? 256 : 1];
 
@@ -550,11 +573,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
     const int rt = a.rt_base + (int)(blockIdx.x % a.n_rt_launch);
-    const int ct = (int)(blockIdx.x / a.n_rt_launch);
+    const int ctw = (int)(blockIdx.x / a.n_rt_launch);  // the workgroup's index among its row tile's workgroups
     const int T = a.T, H = a.H, HO = a.H * a.dirs;
 
-    const bool pw = tid < 256;  // threads that own a (row, 4 columns) piece of the tile's pointwise state
-    const bool pw_wave = NW == 4 || wave < 4;  // the same, as a scalar
+    const bool pw = tid < 256 * CW;  // threads that own a (row, 4 columns) piece of the tile's pointwise state
+    const bool pw_wave = NW == 4 || CW == 2 || wave < 4;  // the same, as a scalar
+    const int cj = CW == 2 ? tid >> 8 : 0;                // this thread's column group within the workgroup
+    const int ct = ctw * CW + cj;                         // ... as a 32-column group of the layer
+    const int cqx = cj * 8 + (tid & 7);                   // index of its column quad in the workgroup's tables
     const int r = (tid & 255) >> 3, cq = tid & 7;
     const int bp = rt * RT + r, col = ct * CT + cq * 4;
     const bool valid = pw && bp < a.Bp && col < H;
@@ -562,24 +588,27 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     const int bpc = min(bp, a.Bp - 1), colc = min(col, H - 4);
     const int d = bpc / a.B, b = bpc - d * a.B;
 
-    u32x4 vb[KGW][2][NP == 3 ? 2 : 1];
+    u32x4 vb[CW][KGW][2][NP == 3 ? 2 : 1];
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
 #pragma unroll
     for (int kk = 0; kk < (EXT ? 0 : KGW); ++kk) {
         const int kg = wave + NW * kk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const u32x4* src = a.vpack + ((((size_t)ct * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
-            vb[kk][ks][0] = src[0];
+            const u32x4* src = a.vpack + ((((size_t)(ctw * CW + c) * a.nkg + kg) * 2 + ks) * 3) * 64 + lane;
+            vb[c][kk][ks][0] = src[0];
             if constexpr (NP == 3) {
-                vb[kk][ks][1] = src[64];
+                vb[c][kk][ks][1] = src[64];
                 vlo[wave][kk][ks][lane] = src[128];
             }
         }
     }
 
     float du_n[4], dw_n[4], u_t[4];
-    if (tid < 16) {  // thread = (direction, column quad)
-        const int dq = tid >> 3, cc = min(ct * CT + (tid & 7) * 4, H - 4), dd = min(dq, a.dirs - 1);
+    if (tid < 16 * CW) {  // thread = (direction, column quad of the workgroup)
+        const int dq = tid / (8 * CW), qx = tid % (8 * CW);
+        const int cc = min(ctw * CW * CT + qx * 4, H - 4), dd = min(dq, a.dirs - 1);
         f32x4 c_al, c_be, c_a, c_b, c_gr;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -589,9 +618,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             c_b[e] = ADAPT ? clampf(a.b[cc + e], SP_B_LO, SP_B_HI) : 0.f;
             c_gr[e] = a.g_rate ? a.g_rate[(size_t)dd * H + cc + e] * a.g_rate_scale : 0.0f;
         }
-        pcol[0][dq][tid & 7] = c_al; pcol[1][dq][tid & 7] = c_be; pcol[2][dq][tid & 7] = c_a;
-        pcol[3][dq][tid & 7] = c_b; pcol[4][dq][tid & 7] = c_gr;
-        if (a.bn_x) { pcol[5][dq][tid & 7] = ld4(a.bn_mean + cc); pcol[6][dq][tid & 7] = ld4(a.bn_invstd + cc); }
+        pcol[0][dq][qx] = c_al; pcol[1][dq][qx] = c_be; pcol[2][dq][qx] = c_a;
+        pcol[3][dq][qx] = c_b; pcol[4][dq][qx] = c_gr;
+        if (a.bn_x) { pcol[5][dq][qx] = ld4(a.bn_mean + cc); pcol[6][dq][qx] = ld4(a.bn_invstd + cc); }
     }
     if (pw && a.t_begin == 0) {
         first_tile[0][tid] = ld4(a.u0 + (size_t)bpc * H + colc);
@@ -630,7 +659,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     }
     if (tid < 2) abort_flag[tid] = 0;
     const unsigned my_xcc = xcc_id();
-    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, SENTINEL, a.n_ct, ct, my_xcc, tid, &xcd_local_flag);
+    xcd_agree((EXT || !a.xcd_tab) ? nullptr : (gu32*)a.xcd_tab + (size_t)rt * a.n_ct, SENTINEL, a.n_ct / CW, ctw, my_xcc, tid, &xcd_local_flag);
     __syncthreads();
     const bool xcd_local = xcd_local_flag != 0;  // this row tile's workgroups share an XCD: plain hand-off stores
 
@@ -670,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     int t_stop = -1;  // the step an abort was seen at (diagnostics of the status word)
     for (int t = a.t_end - 1; t >= a.t_begin; --t) {
         PROF_STAMP(-1);
-        const int pt = tid & 255;
+        const int pt = CW == 2 ? tid : (tid & 255);
         const f32x4 gv = g_nx, xrv = xr_nx;
         f32x4 upv = expand_saved(up_nx), wpv = expand_saved(wp_nx);
         if (t == 0) {  // cell step 0: the initial states (LDS; filled in the prologue when the launch ends at t = 0)
@@ -704,7 +733,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         const size_t o_out = ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
         float pre_ds[4], pre_aldu[4], pre_padw[4];
         auto pre_pointwise = [&]() __attribute__((always_inline)) {
-            const f32x4 al = pcol[0][d][cq], pa = pcol[2][d][cq], pb = pcol[3][d][cq], gr = pcol[4][d][cq];
+            const f32x4 al = pcol[0][d][cqx], pa = pcol[2][d][cqx], pb = pcol[3][d][cqx], gr = pcol[4][d][cqx];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float k = drop ? keep_scale(seed, o_out + e, a.p_drop, a.inv_keep) : 1.0f;
@@ -776,9 +805,11 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #if !REC_BWD_PROBE && REC_BWD_LATE_PREFETCH != 3
             if (pw) pre_pointwise();
 #endif
-            f32x16 acc;
+            f32x16 acc[CW];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int c = 0; c < CW; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KGW; ++kk) {
                 // k-group by k-group: the MFMAs of one run while the loads of the next are still in flight
@@ -791,7 +822,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if constexpr (NP == 1) {  // bf16 operand mode: bf16(dWx) x bf16(V^T), one product
-                        acc = mfma_bf16(raw[kk][ks][0], vb[kk][ks][0], acc);
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) acc[c] = mfma_bf16(raw[kk][ks][0], vb[c][kk][ks][0], acc[c]);
                     } else {
                     const u32x4 p1 = raw[kk][ks][0], p2 = raw[kk][ks][NP - 2], p3 = raw[kk][ks][NP - 1];
                     const u32x4 vl = vlo[wave][kk][ks][lane];
@@ -800,12 +832,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
                     // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
                     // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
-                    acc = mfma_bf16(p2, vb[kk][ks][NP == 3], acc);  // t2*mid
-                    acc = mfma_bf16(p3, vb[kk][ks][0], acc);  // t3*hi
-                    acc = mfma_bf16(p1, vl, acc);             // t1*lo
-                    acc = mfma_bf16(p2, vb[kk][ks][0], acc);  // t2*hi
-                    acc = mfma_bf16(p1, vb[kk][ks][NP == 3], acc);  // t1*mid
-                    acc = mfma_bf16(p1, vb[kk][ks][0], acc);  // t1*hi
+                    acc[0] = mfma_bf16(p2, vb[0][kk][ks][NP == 3], acc[0]);  // t2*mid
+                    acc[0] = mfma_bf16(p3, vb[0][kk][ks][0], acc[0]);  // t3*hi
+                    acc[0] = mfma_bf16(p1, vl, acc[0]);       // t1*lo
+                    acc[0] = mfma_bf16(p2, vb[0][kk][ks][0], acc[0]);  // t2*hi
+                    acc[0] = mfma_bf16(p1, vb[0][kk][ks][NP == 3], acc[0]);  // t1*mid
+                    acc[0] = mfma_bf16(p1, vb[0][kk][ks][0], acc[0]);  // t1*hi
                     }
                 }
             }
@@ -815,11 +847,14 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #if REC_BWD_LATE_PREFETCH == 3
             if (pw) pre_pointwise();
 #endif
-            float* rd = red[wave];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                rd[row * RED_LD4 + li] = acc[i];
+            for (int c = 0; c < CW; ++c) {
+                float* rd = red[wave][c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    rd[row * RED_LD4 + li] = acc[c][i];
+                }
             }
             PROF_STAMP(1);  // per k-group: wait, split, MFMA; LDS write
         }
@@ -871,10 +906,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             const f32x4 v = ld4(a.rec0 + (size_t)bpc * H + colc);
             rec[0] = v.x; rec[1] = v.y; rec[2] = v.z; rec[3] = v.w;
         } else if (t + 1 < T) {
-            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[0][r * RED_LD4 + cq * 4]);  // (see the forward)
+            f32x4 sum = *reinterpret_cast<const f32x4*>(&red[0][cj][r * RED_LD4 + cq * 4]);  // (see the forward)
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][r * RED_LD4 + cq * 4]);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][cj][r * RED_LD4 + cq * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sum[e] = sum[e] + v[e];
             }
@@ -891,7 +926,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             const f32x4 v = first_tile[2][pt];
             sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
         }
-        const f32x4 al = pcol[0][d][cq], be = pcol[1][d][cq];
+        const f32x4 al = pcol[0][d][cqx], be = pcol[1][d][cqx];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ds = pre_ds[e] + rec[e];
@@ -1000,7 +1035,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
             if (ADAPT) { PACC(1, pt) = v_be; PACC(2, pt) = v_a; PACC(3, pt) = v_b; }
             if (bn) {  // BatchNorm backward's column sums (dy = dWx, xhat = (x - mean) * invstd)
                 f32x4 v_dy = PACC(4, pt), v_dyx = PACC(5, pt);
-                const f32x4 mu = pcol[5][d][cq], is = pcol[6][d][cq];
+                const f32x4 mu = pcol[5][d][cqx], is = pcol[6][d][cqx];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v_dy[e] += dwx[e];
@@ -1035,7 +1070,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     if (valid) {
         f32x4 v = PACC(0, tid);
         if (a.t_begin == 0) {  // last chunk of the pass: d u_t / d alpha = (q - u_t) / (1 - alpha)
-            const f32x4 al = pcol[0][d][cq];
+            const f32x4 al = pcol[0][d][cqx];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f - al[e]);
         }
@@ -1391,7 +1426,24 @@ bool xcd_local_enabled() {
 
 // NP = 1: the bf16 operand mode (sparch_set_operand_precision) — the V pack then holds one rounded plane
 template <bool BWD, bool ADAPT, int NP = 3>
-int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
+int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st, int cw = 1) {
+    if constexpr (NP == 1) {
+        if (cw == 2) {  // 64-column workgroups (bf16 operand mode, 8-wave kernels: kgw >= 2)
+#define SP_LAUNCH2(KB)                                                                                \
+    if (BWD && a.save16) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, 8, false, 1, true, 2>), dim3(grid), dim3(512), 0, st, a); \
+    else if (BWD) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, 8, false, 1, false, 2>), dim3(grid), dim3(512), 0, st, a); \
+    else     hipLaunchKernelGGL((rec_fwd_kernel<ADAPT, KB, 8, false, 1, 2>), dim3(grid), dim3(512), 0, st, a);
+            switch (kgw) {
+                case 2: SP_LAUNCH2(1) break;
+                case 4: SP_LAUNCH2(2) break;
+                case 8: SP_LAUNCH2(4) break;
+                default: return SPARCH_EINVAL;
+            }
+#undef SP_LAUNCH2
+            SPARCH_CHECK_LAUNCH();
+            return SPARCH_OK;
+        }
+    }
     // 8 waves of K/2 k-groups each once there are at least 8 k-groups, else 4 waves
 #define SP_LAUNCH(K, KB, NWB)                                                                        \
     if (BWD && a.save16) hipLaunchKernelGGL((rec_bwd_kernel<ADAPT, KB, NWB, false, NP, true>), dim3(grid), dim3(64 * NWB), 0, st, a); \
@@ -1410,7 +1462,21 @@ int launch_rec(int kgw, const RecArgs& a, unsigned grid, hipStream_t st) {
 }
 
 template <bool BWD, bool ADAPT, int NP = 3>
-bool rec_co_resident(int kgw, unsigned grid, int cus) {
+bool rec_co_resident(int kgw, unsigned grid, int cus, int cw = 1) {
+    if constexpr (NP == 1) {
+        if (cw == 2) {
+#define SP_RES2(KB) \
+    return BWD ? grid_is_co_resident<rec_bwd_kernel<ADAPT, KB, 8, false, 1, false, 2>>(grid, 512, cus) \
+               : grid_is_co_resident<rec_fwd_kernel<ADAPT, KB, 8, false, 1, 2>>(grid, 512, cus);
+            switch (kgw) {
+                case 2: SP_RES2(1)
+                case 4: SP_RES2(2)
+                case 8: SP_RES2(4)
+                default: return false;
+            }
+#undef SP_RES2
+        }
+    }
 #define SP_RES(KB, NWB) \
     return BWD ? grid_is_co_resident<rec_bwd_kernel<ADAPT, KB, NWB, false, NP>>(grid, 64 * NWB, cus) \
                : grid_is_co_resident<rec_fwd_kernel<ADAPT, KB, NWB, false, NP>>(grid, 64 * NWB, cus);
@@ -1455,37 +1521,48 @@ int run_rec(int kind, RecArgs& a, size_t chan_bytes, int steps_per_launch, hipSt
     int cus = sparch_device_cus();
     if (cus <= 0) cus = 256;
     int rt_per_launch;
+    // 64-column workgroups (bf16 operand mode): when the row tiles do not fit one persistent launch at 32 columns
+    // per workgroup (512 virtual rows at H = 1024: 16 x 32 workgroups) but do at 64 (16 x 16), the whole batch runs
+    // as ONE launch instead of two half-machine launches back to back — the steps are latency chains, so a launch
+    // over all rows takes about as long as one over half of them.  SPARCH_REC_CW=1 forces the 32-column kernels.
+    static const int cw_env = [] { const char* e = getenv("SPARCH_REC_CW"); return e ? atoi(e) : 0; }();
+    int cw = 1;
+    if (low && L > 1 && kgw >= 2 && a.n_ct % 2 == 0 && cw_env != 1 &&
+        (cw_env == 2 || ((long long)a.n_rt_total * a.n_ct > cus && (long long)a.n_rt_total * (a.n_ct / 2) <= cus)))
+        cw = 2;
+    const int wg_per_rt = a.n_ct / cw;  // workgroups of one row tile
     if (L == 1) {
         rt_per_launch = a.n_rt_total;  // nothing waits inside a launch: any grid size is fine
     } else {
-        rt_per_launch = cus / a.n_ct;  // one workgroup per CU must be co-resident
+        rt_per_launch = cus / wg_per_rt;  // one workgroup per CU must be co-resident
         if (rt_per_launch < 1) { L = 1; rt_per_launch = a.n_rt_total; }
     }
     if (L > 1) {  // ask the runtime's occupancy calculator instead of assuming one workgroup per CU fits
-        const unsigned g = (unsigned)(a.n_ct * min(rt_per_launch, a.n_rt_total));
-        const bool ok = low ? (adapt ? rec_co_resident<BWD, true, 1>(kgw, g, cus) : rec_co_resident<BWD, false, 1>(kgw, g, cus))
+        const unsigned g = (unsigned)(wg_per_rt * min(rt_per_launch, a.n_rt_total));
+        const bool ok = low ? (adapt ? rec_co_resident<BWD, true, 1>(kgw, g, cus, cw) : rec_co_resident<BWD, false, 1>(kgw, g, cus, cw))
                             : (adapt ? rec_co_resident<BWD, true>(kgw, g, cus) : rec_co_resident<BWD, false>(kgw, g, cus));
         if (!ok) {
             if (a.save16 && !BWD) return SPARCH_EINVAL;  // bf16 saves need the whole-sequence forward launch
             L = 1; rt_per_launch = a.n_rt_total;
         }
     }
+    if (L == 1) cw = 1;
     if (L < a.T || !xcd_local_enabled()) a.xcd_tab = nullptr;  // whole-sequence launches only (one agreement per launch)
     for (int rt0 = 0; rt0 < a.n_rt_total; rt0 += rt_per_launch) {
         a.rt_base = rt0;
         a.n_rt_launch = min(rt_per_launch, a.n_rt_total - rt0);
-        const unsigned grid = (unsigned)(a.n_ct * a.n_rt_launch);
+        const unsigned grid = (unsigned)((a.n_ct / cw) * a.n_rt_launch);
         if (!BWD) {
             for (int t0 = 0; t0 < a.T; t0 += L) {
                 a.t_begin = t0; a.t_end = min(a.T, t0 + L);
-                int rc = low ? (adapt ? launch_rec<false, true, 1>(kgw, a, grid, st) : launch_rec<false, false, 1>(kgw, a, grid, st))
+                int rc = low ? (adapt ? launch_rec<false, true, 1>(kgw, a, grid, st, cw) : launch_rec<false, false, 1>(kgw, a, grid, st, cw))
                              : (adapt ? launch_rec<false, true>(kgw, a, grid, st) : launch_rec<false, false>(kgw, a, grid, st));
                 if (rc != SPARCH_OK) return rc;
             }
         } else {
             for (int t1 = a.T; t1 > 0; t1 -= L) {
                 a.t_end = t1; a.t_begin = max(0, t1 - L);
-                int rc = low ? (adapt ? launch_rec<true, true, 1>(kgw, a, grid, st) : launch_rec<true, false, 1>(kgw, a, grid, st))
+                int rc = low ? (adapt ? launch_rec<true, true, 1>(kgw, a, grid, st, cw) : launch_rec<true, false, 1>(kgw, a, grid, st, cw))
                              : (adapt ? launch_rec<true, true>(kgw, a, grid, st) : launch_rec<true, false>(kgw, a, grid, st));
                 if (rc != SPARCH_OK) return rc;
             }
