@@ -67,20 +67,21 @@ const char* sparch_last_hip_error(void);
 /* Number of compute units / XCDs the library sizes its persistent grids for. */
 int sparch_device_cus(void);
 
-/* Operand precision of every matrix product of the library: the GEMMs below and the recurrent cells'
- * s_{t-1} @ V / dWx_{t+1} @ V^T (G3/G4).  The reference has no such switch (it is fp32-only: snns.py:29 casts the
- * spikes to float and snns.py:572 then requires a float V); BASELINE.json configs[4] names a bf16 run.
- *   SPARCH_PRECISION_FP32_EXACT (default): fp32 operands split exactly into bf16 planes, exact products, fp32
- *       accumulation — fp32 results.
+/* Operand precision of a matrix product: the `precision` argument — the last one — of every entry point that
+ * multiplies (the split GEMMs below, the V packs, the recurrent cells' s_{t-1} @ V / dWx_{t+1} @ V^T, G3/G4).  The
+ * reference has no such choice (it is fp32-only: snns.py:29 casts the spikes to float and snns.py:572 then requires
+ * a float V); BASELINE.json configs[4] names a bf16 run.
+ *   SPARCH_PRECISION_FP32_EXACT: fp32 operands split exactly into bf16 planes, exact products, fp32 accumulation —
+ *       fp32 results.
  *   SPARCH_PRECISION_BF16: every fp32 operand is rounded ONCE to bf16 (nearest-even) as it is staged, one bf16
  *       MFMA per product, fp32 accumulation; states, statistics, outputs and parameter updates stay fp32.
  *       Spike operands (0 / 1) and bf16-representable weights lose nothing: a network whose weights are
  *       bf16-exact has a bit-identical forward pass in both modes.
- * Process-wide; set it between steps.  Returns SPARCH_EINVAL for an unknown mode. */
+ * Per call (ABI v5): the library keeps no precision state — rounds 1-2 had a process-wide
+ * sparch_set_operand_precision().  A V pack must be consumed by cell calls of the precision it was made with; a
+ * *_workspace_bytes query takes the precision of the call it sizes.  Unknown value: SPARCH_EINVAL (0 bytes). */
 #define SPARCH_PRECISION_FP32_EXACT 0
 #define SPARCH_PRECISION_BF16 1
-int sparch_set_operand_precision(int mode);
-int sparch_get_operand_precision(void);
 
 /* ------------------------------------------------------------------------------------
  * G1  feed-forward projection  (replaces `self.W(x)` = nn.Linear, snns.py:261/398/533/675/796,
@@ -114,8 +115,8 @@ int sparch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B,
  *   spike_tn: C[M,N] (+)= scale * A[K,M]^T * B[K,N], spike_side 0: A is the spike operand, 1: B. */
 int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int lda, float scale,
                          const float* B, int ldb, float* C, int ldc, const float* bias,
-                         float* colstat_ws, void* stream);
-size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K);
+                         float* colstat_ws, void* stream, int precision);
+size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K, int precision);
 
 /* The same products with the spike operand given as a bf16 PLANE (uint16 bit patterns, entries 0 or
  * 0x3F80 = 1.0; any bf16 value is taken as is): the cell kernels write this plane next to their fp32
@@ -124,10 +125,10 @@ size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K);
  * workspace as sparch_gemm_spike_tn_workspace_bytes.                                               */
 int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
                            const float* B, int ldb, float* C, int ldc, const float* bias,
-                           float* colstat_ws, void* stream);
+                           float* colstat_ws, void* stream, int precision);
 int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                            int spike_side, float scale, float* C, int ldc, int zero_diag,
-                           int accumulate, void* ws, size_t ws_bytes, void* stream);
+                           int accumulate, void* ws, size_t ws_bytes, void* stream, int precision);
 
 /* Dense x dense products on the same exact-split machinery: BOTH fp32 operands are split into three
  * bf16 planes and the six largest cross terms are accumulated in fp32 (the rest measures ~1e-8 of
@@ -136,18 +137,18 @@ int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const vo
 /* Split-K forms for small M*N with a long K (per-step recurrent products of the gated baselines): the
  * contraction is cut into slabs in `ws` (sparch_gemm6_splitk_workspace_bytes; 0 = not needed) and reduced in
  * fixed order.  No bias / statistics epilogue.                                                         */
-size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K);
+size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K, int precision);
 int sparch_gemm6_nt_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream);
+                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream, int precision);
 int sparch_gemm6_nn_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream);
+                           float* C, int ldc, void* ws, size_t ws_bytes, void* stream, int precision);
 int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, const float* bias, float* colstat_ws, void* stream);
+                    float* C, int ldc, const float* bias, float* colstat_ws, void* stream, int precision);
 int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, void* stream);
+                    float* C, int ldc, void* stream, int precision);
 int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes,
-                    void* stream);
+                    void* stream, int precision);
 
 /* Weight operands pre-split into their bf16 planes.  A spiking layer's W (H x K) is the B operand of its
  * projection (snns.py:261, x W^T) and of backward's dx = dWx W; both kernels would re-convert the same
@@ -159,9 +160,9 @@ int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B
 int sparch_split3(size_t n, const float* x, uint16_t* planes, void* stream);
 int sparch_gemm_spike16_nt_wp(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
                               const float* B, const uint16_t* B_planes, int ldb, float* C, int ldc,
-                              const float* bias, float* colstat_ws, void* stream);
+                              const float* bias, float* colstat_ws, void* stream, int precision);
 int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, const float* B,
-                       const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream);
+                       const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream, int precision);
 
 /* First-layer input (snns.py:261 on the network input): SHD/SSC-style binned spike counts are small
  * integers, exactly representable in bf16, but the library cannot know that on the host.
@@ -172,10 +173,10 @@ int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, const float
 int sparch_flag_bf16_exact(size_t n, const float* x, uint32_t* flag, void* stream);
 int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, float* colstat_ws,
-                        const uint32_t* a_exact_flag, void* stream);
+                        const uint32_t* a_exact_flag, void* stream, int precision);
 int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, int zero_diag, int accumulate,
-                        const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream);
+                        const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream, int precision);
 /* The same with the flagged operand's bf16 plane made by the check itself: sparch_plane_bf16_exact writes
  * plane[m][k] = upper 16 bits of x[m][k] (the exact value whenever the flag stays 1; rows of ldp >= K elements,
  * ldp % 8 == 0, columns K.. zero) in the pass that computes the flag, and the _auto16_ GEMMs read that plane
@@ -185,13 +186,13 @@ int sparch_plane_bf16_exact(int M, int K, const float* x, int ldx, uint16_t* pla
                             void* stream);
 int sparch_gemm_auto16_nt(int M, int N, int K, const float* A, int lda, const uint16_t* A16, int lda16,
                           const float* B, int ldb, float* C, int ldc, const float* bias, float* colstat_ws,
-                          const uint32_t* a_exact_flag, void* stream);
+                          const uint32_t* a_exact_flag, void* stream, int precision);
 int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                           const uint16_t* B16, int ldb16, float* C, int ldc, int zero_diag, int accumulate,
-                          const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream);
+                          const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream, int precision);
 int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          int spike_side, float scale, float* C, int ldc, int zero_diag,
-                         int accumulate, void* ws, size_t ws_bytes, void* stream);
+                         int accumulate, void* ws, size_t ws_bytes, void* stream, int precision);
 
 /* ------------------------------------------------------------------------------------
  * G2  normalisation on the (M = B*T, H) view  (replaces nn.BatchNorm1d(momentum=0.05) /
@@ -301,10 +302,10 @@ int sparch_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_out,
 size_t sparch_vpack_bytes(int H);
 /* transpose: bit 0 = pack V^T, bit 1 = keep the diagonal (dense cells of the ANN baselines) */
 int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked,
-                 void* stream);
+                 void* stream, int precision);
 /* The forward fragments, the backward (transposed) fragments and the masked copy in one launch (a training step
  * needs all three; vmasked may be NULL).                                                                    */
-int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream);
+int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream, int precision);
 /* vmasked (H,H) = V with its diagonal zeroed (snns.py:566/712), any H */
 int sparch_vmask(int H, const float* V, float* vmasked, void* stream);
 /* XCD-local hand-off stores of the spiking recurrent kernels (whole-sequence launches): the workgroups of a row
@@ -321,7 +322,7 @@ int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, const float* Wx
                         const float* w0, const float* s0, float theta, float p_drop,
                         uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save,
                         void* w_save, int save_bf16, uint32_t* spike_count, void* chan,
-                        size_t chan_bytes, uint32_t* status, int steps_per_launch, void* stream);
+                        size_t chan_bytes, uint32_t* status, int steps_per_launch, void* stream, int precision);
 /* Backward: each step's 32x32 dWx tile is handed to the other workgroups through `chan`.
  * s_prev16 (Bp,T,H) receives s_{t-1} as a bf16 plane (binary for t >= 1, a zero row at
  * t = 0: the non-binary s0 term is added by the caller) for dV = s_prev^T * dWx
@@ -336,7 +337,7 @@ int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, const float* g_
                         uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
                         const float* bn_x, const float* bn_mean, const float* bn_invstd,
                         void* chan, size_t chan_bytes, uint32_t* status,
-                        int steps_per_launch, void* stream);
+                        int steps_per_launch, void* stream, int precision);
 /* ONE time step t of the same cells with the recurrent product supplied by the caller — the path for hidden
  * sizes whose V slice does not fit the persistent kernels' register-resident layout (H > 1024; the reference
  * accepts any nb_hiddens, snns.py:608-661): any grid size, nothing waits inside a launch.
@@ -467,7 +468,7 @@ int sparch_ann_rec_step_bwd(int act, int B, int dirs, int T, int H, int s, const
  * projections, yprev_all = y_{t-1} (dVz = dz_all^T yprev_all, dV = dc_all^T yprev_all); carry (Bp,H): scratch
  * carried between chunked launches.  chan: sparch_ligru_chan_bytes(Bp, H) of scratch.                  */
 size_t sparch_ligru_vpack_bytes(int H, int backward);
-int sparch_ligru_vpack(int H, const float* Vz, const float* V, int backward, float* vpack, void* stream);
+int sparch_ligru_vpack(int H, const float* Vz, const float* V, int backward, float* vpack, void* stream, int precision);
 size_t sparch_ligru_chan_bytes(int Bp, int H);
 int sparch_ligru_fwd(int B, int dirs, int T, int H, const float* Wx, const float* sc, const float* sh,
                      const float* Wzx, const float* scz, const float* shz, const float* vpack,
@@ -499,7 +500,7 @@ int sparch_mt19937_uniform_f32(uint32_t* key, int* pos, size_t n, float* out);
  * count — callers then use the launch-per-step path (sparch_gate_step).  chan: sparch_gru_chan_bytes(Bp, H).  */
 size_t sparch_gru_vpack_bytes(int H, int backward, int which);
 int sparch_gru_vpack(int H, const float* Vz, const float* Vr, const float* V, int backward, float* vpack_gate,
-                     float* vpack_cand, void* stream);
+                     float* vpack_cand, void* stream, int precision);
 size_t sparch_gru_chan_bytes(int Bp, int H);
 int sparch_gru_fwd(int B, int dirs, int T, int H, const float* Wx, const float* sc, const float* sh,
                    const float* Wzx, const float* scz, const float* shz, const float* Wrx, const float* scr,

@@ -31,36 +31,34 @@ PROTOTYPES = {
     "sparch_strerror": (c_char_p, [c_int]),
     "sparch_last_hip_error": (c_char_p, []),
     "sparch_device_cus": (c_int, []),
-    "sparch_set_operand_precision": (c_int, [c_int]),
-    "sparch_get_operand_precision": (c_int, []),
     "sparch_gemm_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "sparch_gemm_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
     "sparch_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sparch_gemm_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),
-    "sparch_gemm_spike_nt": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, c_int, P, P, P]),
-    "sparch_gemm_spike_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "sparch_gemm_spike16_nt": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, c_int, P, P, P]),
+    "sparch_gemm_spike_nt": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, c_int, P, P, P, c_int]),
+    "sparch_gemm_spike_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sparch_gemm_spike16_nt": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, c_int, P, P, P, c_int]),
     "sparch_gemm_spike16_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_float, P, c_int, c_int,
-                                       c_int, P, c_size_t, P]),
+                                       c_int, P, c_size_t, P, c_int]),
     "sparch_gemm_spike_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_float, P, c_int, c_int,
-                                     c_int, P, c_size_t, P]),
-    "sparch_gemm6_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "sparch_gemm6_nt_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P]),
-    "sparch_gemm6_nn_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P]),
-    "sparch_gemm6_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
-    "sparch_gemm6_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P]),
+                                     c_int, P, c_size_t, P, c_int]),
+    "sparch_gemm6_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sparch_gemm6_nt_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P, c_int]),
+    "sparch_gemm6_nn_splitk": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_size_t, P, c_int]),
+    "sparch_gemm6_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, c_int]),
+    "sparch_gemm6_nn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int]),
     "sparch_split3": (c_int, [c_size_t, P, P, P]),
-    "sparch_gemm_spike16_nt_wp": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, P, c_int, P, c_int, P, P, P]),
-    "sparch_gemm6_nn_wp": (c_int, [c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, P]),
-    "sparch_gemm6_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "sparch_gemm_spike16_nt_wp": (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, P, c_int, P, c_int, P, P, P, c_int]),
+    "sparch_gemm6_nn_wp": (c_int, [c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, P, c_int]),
+    "sparch_gemm6_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P, c_int]),
     "sparch_flag_bf16_exact": (c_int, [c_size_t, P, P, P]),
-    "sparch_gemm_auto_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),
+    "sparch_gemm_auto_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int]),
     "sparch_gemm_auto_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P,
-                                    c_size_t, P]),
+                                    c_size_t, P, c_int]),
     "sparch_plane_bf16_exact": (c_int, [c_int, c_int, P, c_int, P, c_int, P, P]),
-    "sparch_gemm_auto16_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P]),
+    "sparch_gemm_auto16_nt": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int]),
     "sparch_gemm_auto16_tn": (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int,
-                                      P, P, c_size_t, P]),
+                                      P, P, c_size_t, P, c_int]),
     "sparch_bn_finalize": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, c_float, c_int,
                                    P, P, P, P, P, P, P]),
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -74,14 +72,14 @@ PROTOTYPES = {
                                 c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "sparch_vpack_bytes": (c_size_t, [c_int]),
     "sparch_set_xcd_local": (c_int, [c_int]),
-    "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P]),
-    "sparch_vpack_both": (c_int, [c_int, P, P, P, P, P]),
+    "sparch_vpack": (c_int, [c_int, P, c_int, P, P, P, c_int]),
+    "sparch_vpack_both": (c_int, [c_int, P, P, P, P, P, c_int]),
     "sparch_vmask": (c_int, [c_int, P, P, P]),
     "sparch_rec_chan_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sparch_rec_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
-                                    c_float, c_float, c_uint64, P, P, P, P, c_int, P, P, c_size_t, P, c_int, P]),
+                                    c_float, c_float, c_uint64, P, P, P, P, c_int, P, P, c_size_t, P, c_int, P, c_int]),
     "sparch_rec_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P,
-                                    c_float, c_float, c_uint64, P, P, P, P, P, P, P, c_size_t, P, c_int, P]),
+                                    c_float, c_float, c_uint64, P, P, P, P, P, P, P, c_size_t, P, c_int, P, c_int]),
     "sparch_rec_cell_step_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
                                          c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
     "sparch_rec_cell_step_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P,
@@ -107,7 +105,7 @@ PROTOTYPES = {
     "sparch_ann_rec_step_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, c_uint64, P, P, P,
                                         P]),
     "sparch_ligru_vpack_bytes": (c_size_t, [c_int, c_int]),
-    "sparch_ligru_vpack": (c_int, [c_int, P, P, c_int, P, P]),
+    "sparch_ligru_vpack": (c_int, [c_int, P, P, c_int, P, P, c_int]),
     "sparch_ligru_chan_bytes": (c_size_t, [c_int, c_int]),
     "sparch_ligru_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_float, c_uint64, P, P, P, P, P,
                                  c_size_t, P, c_int, P]),
@@ -115,7 +113,7 @@ PROTOTYPES = {
                                  c_size_t, P, c_int, P]),
     "sparch_mt19937_uniform_f32": (c_int, [P, P, c_size_t, P]),
     "sparch_gru_vpack_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "sparch_gru_vpack": (c_int, [c_int, P, P, P, c_int, P, P, P]),
+    "sparch_gru_vpack": (c_int, [c_int, P, P, P, c_int, P, P, P, c_int]),
     "sparch_gru_chan_bytes": (c_size_t, [c_int, c_int]),
     "sparch_gru_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, c_float, c_uint64, P, P, P,
                                P, P, P, c_size_t, P, c_int, P]),

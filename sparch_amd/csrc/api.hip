@@ -10,19 +10,20 @@ void sparch_note_hip_error(int e) { g_last_hip_error = e; }
 // 4: sparch_set_operand_precision (bf16 operands, fp32 accumulation) for the GEMMs and the recurrent cells
 // 5: s_out optional in the cell forwards; the status word is SPARCH_STATUS_WORDS uint32 (raised, skipped optimizer
 //    steps, kernel id, time step); sparch_bn_finalize takes BatchNorm's num_batches_tracked; sparch_adam_step
-//    counts the steps it skips
+//    counts the steps it skips; operand precision is a per-call argument (sparch_set_operand_precision is gone)
 extern "C" int sparch_abi_version(void) { return 5; }
 
-// Process-wide operand precision of every matrix product of the library (GEMMs and the recurrent cells'
-// s @ V / dWx @ V^T): set between steps, never while launches are being enqueued from another thread.
-static int g_operand_precision = SPARCH_PRECISION_FP32_EXACT;
-int sparch_operand_bf16(void) { return g_operand_precision == SPARCH_PRECISION_BF16; }
-extern "C" int sparch_set_operand_precision(int mode) {
-    if (mode != SPARCH_PRECISION_FP32_EXACT && mode != SPARCH_PRECISION_BF16) return SPARCH_EINVAL;
-    g_operand_precision = mode;
-    return SPARCH_OK;
+// Operand precision of the matrix products: a PER-CALL argument of every entry point that multiplies (ABI v5; rounds
+// 1-2 had a process-wide switch, sparch_set_operand_precision).  The entry point opens a PrecisionScope for the
+// duration of the call — a thread-local the dispatch helpers below it read — so two models of different precision in
+// one process, or two host threads, never see each other's setting, and nothing outlives the call.
+static thread_local int tl_operand_precision = SPARCH_PRECISION_FP32_EXACT;
+int sparch_operand_bf16(void) { return tl_operand_precision == SPARCH_PRECISION_BF16; }
+PrecisionScope::PrecisionScope(int precision)
+    : prev(tl_operand_precision), ok(precision == SPARCH_PRECISION_FP32_EXACT || precision == SPARCH_PRECISION_BF16) {
+    if (ok) tl_operand_precision = precision;
 }
-extern "C" int sparch_get_operand_precision(void) { return g_operand_precision; }
+PrecisionScope::~PrecisionScope() { tl_operand_precision = prev; }
 
 extern "C" const char* sparch_last_hip_error(void) {
     return hipGetErrorString((hipError_t)g_last_hip_error);

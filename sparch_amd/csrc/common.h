@@ -19,9 +19,18 @@ void sparch_note_hip_error(int hip_error);
         if (e_ != hipSuccess) { sparch_note_hip_error((int)e_); return SPARCH_ELAUNCH; } \
     } while (0)
 
-// Operand precision of the matrix products (sparch_set_operand_precision): 0 = exact fp32 through bf16 splits
-// (default), 1 = operands rounded to bf16 once (round-to-nearest-even), fp32 accumulation — BASELINE configs[4].
+// Operand precision of the matrix products (the `precision` argument of the entry points): 0 = exact fp32 through
+// bf16 splits, 1 = operands rounded to bf16 once (round-to-nearest-even), fp32 accumulation — BASELINE configs[4].
+// An entry point opens a PrecisionScope for the call; the dispatch code below it asks sparch_operand_bf16().
 int sparch_operand_bf16(void);
+struct PrecisionScope {
+    int prev;
+    bool ok;  // false: unknown precision value (the caller returns SPARCH_EINVAL)
+    explicit PrecisionScope(int precision);
+    ~PrecisionScope();
+    PrecisionScope(const PrecisionScope&) = delete;
+    PrecisionScope& operator=(const PrecisionScope&) = delete;
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1045,8 +1045,10 @@ extern "C" size_t sparch_ligru_vpack_bytes(int H, int backward) {
     return backward ? n_ct * (8 * kgw) * 3 * 64 * sizeof(u32x4) : n_ct * (8 * kgw) * 2 * 3 * 64 * sizeof(u32x4);
 }
 
-extern "C" int sparch_ligru_vpack(int H, const float* Vz, const float* V, int backward, float* vpack, void* stream) {
+extern "C" int sparch_ligru_vpack(int H, const float* Vz, const float* V, int backward, float* vpack, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (sparch_ligru_vpack_bytes(H, backward) == 0 || !Vz || !V || !vpack) return SPARCH_EINVAL;
     if (!aligned16(vpack)) return SPARCH_EALIGN;
     const int n_ct = H / UT;
@@ -1124,11 +1126,13 @@ extern "C" size_t sparch_gru_vpack_bytes(int H, int backward, int which) {
 }
 
 extern "C" int sparch_gru_vpack(int H, const float* Vz, const float* Vr, const float* V, int backward, float* vpack_gate,
-                                float* vpack_cand, void* stream) {
+                                float* vpack_cand, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (sparch_gru_vpack_bytes(H, backward, 0) == 0 || !Vz || !Vr || !V || !vpack_gate || !vpack_cand) return SPARCH_EINVAL;
     if (!aligned16(vpack_gate) || !aligned16(vpack_cand)) return SPARCH_EALIGN;
-    const int rc = sparch_ligru_vpack(H, Vz, Vr, backward, vpack_gate, stream);
+    const int rc = sparch_ligru_vpack(H, Vz, Vr, backward, vpack_gate, stream, precision);
     if (rc != SPARCH_OK) return rc;
     const int n_ct = H / UT;
     const int kgw = backward ? kgw_bwd(H) : kgw_fwd(H);

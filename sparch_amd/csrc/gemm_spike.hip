@@ -851,8 +851,10 @@ extern "C" int sparch_split3(size_t n, const float* x, uint16_t* planes, void* s
 
 extern "C" int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int lda, float scale, const float* B,
                                     int ldb, float* C, int ldc, const float* bias, float* colstat_ws,
-                                    void* stream) {
+                                    void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A_spk || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = A_spk; g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
@@ -868,8 +870,10 @@ extern "C" int sparch_gemm_spike_nt(int M, int N, int K, const float* A_spk, int
 
 extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                     int spike_side, float scale, float* C, int ldc, int zero_diag,
-                                    int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                                    int accumulate, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     if (spike_side != 0 && spike_side != 1) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -896,8 +900,10 @@ extern "C" int sparch_gemm_spike_tn(int M, int N, int K, const float* A, int lda
 // output): same products, half the operand bytes
 extern "C" int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
                                       const float* B, int ldb, float* C, int ldc, const float* bias,
-                                      float* colstat_ws, void* stream) {
+                                      float* colstat_ws, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A_spk16 || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = reinterpret_cast<const float*>(A_spk16); g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
@@ -913,8 +919,10 @@ extern "C" int sparch_gemm_spike16_nt(int M, int N, int K, const uint16_t* A_spk
 
 extern "C" int sparch_gemm_spike16_nt_wp(int M, int N, int K, const uint16_t* A_spk16, int lda, float scale,
                                          const float* B, const uint16_t* B_planes, int ldb, float* C, int ldc,
-                                         const float* bias, float* colstat_ws, void* stream) {
+                                         const float* bias, float* colstat_ws, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A_spk16 || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = reinterpret_cast<const float*>(A_spk16); g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
@@ -930,8 +938,10 @@ extern "C" int sparch_gemm_spike16_nt_wp(int M, int N, int K, const uint16_t* A_
 }
 
 extern "C" int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, const float* B,
-                                  const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream) {
+                                  const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = A; g.B = B; g.C = C; g.Bp = B_planes; g.bp_stride = (size_t)K * ldb;
@@ -944,8 +954,10 @@ extern "C" int sparch_gemm6_nn_wp(int M, int N, int K, const float* A, int lda, 
 
 extern "C" int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                       int spike_side, float scale, float* C, int ldc, int zero_diag,
-                                      int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                                      int accumulate, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     if (spike_side != 0 && spike_side != 1) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -971,8 +983,10 @@ extern "C" int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int ld
 
 // ---- dense x dense on the exact 6-term split (same signatures as the fp32-MFMA entry points in gemm.hip)
 extern "C" int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                               int ldc, const float* bias, float* colstat_ws, void* stream) {
+                               int ldc, const float* bias, float* colstat_ws, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.colstat = colstat_ws;
@@ -987,8 +1001,10 @@ extern "C" int sparch_gemm6_nt(int M, int N, int K, const float* A, int lda, con
 }
 
 extern "C" int sparch_gemm6_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                               int ldc, void* stream) {
+                               int ldc, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
     SArgs g{};
     g.A = A; g.B = B; g.C = C;
@@ -1036,27 +1052,35 @@ int gemm6_splitk(int M, int N, int K, const float* A, int lda, const float* B, i
 }
 }  // namespace
 
-extern "C" size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K) {
+extern "C" size_t sparch_gemm6_splitk_workspace_bytes(int M, int N, int K, int precision) {
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return 0;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int s = small_splits(M, N, K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 extern "C" int sparch_gemm6_nt_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream) {
+                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N) return SPARCH_EINVAL;
     return gemm6_splitk<false>(M, N, K, A, lda, B, ldb, C, ldc, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int sparch_gemm6_nn_splitk(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream) {
+                                      float* C, int ldc, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
     return gemm6_splitk<true>(M, N, K, A, lda, B, ldb, C, ldc, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sparch_gemm6_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                               int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                               int ldc, int zero_diag, int accumulate, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int splits = choose_splits<2>(M, N, K);
@@ -1106,8 +1130,10 @@ extern "C" int sparch_flag_bf16_exact(size_t n, const float* x, uint32_t* flag, 
 
 extern "C" int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                    float* C, int ldc, const float* bias, float* colstat_ws,
-                                   const uint32_t* a_exact_flag, void* stream) {
+                                   const uint32_t* a_exact_flag, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < K || ldb < K || ldc < N || !a_exact_flag)
         return SPARCH_EINVAL;
     SArgs g{};
@@ -1130,8 +1156,10 @@ extern "C" int sparch_gemm_auto_nt(int M, int N, int K, const float* A, int lda,
 
 extern "C" int sparch_gemm_auto_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                    float* C, int ldc, int zero_diag, int accumulate,
-                                   const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream) {
+                                   const uint32_t* b_exact_flag, void* ws, size_t ws_bytes, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N || !b_exact_flag)
         return SPARCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -1200,8 +1228,10 @@ extern "C" int sparch_plane_bf16_exact(int M, int K, const float* x, int ldx, ui
 // plane (2 bytes per element, no conversion); flag == 0 -> the six-term kernel on the fp32 operand, as before.
 extern "C" int sparch_gemm_auto16_nt(int M, int N, int K, const float* A, int lda, const uint16_t* A16, int lda16,
                                      const float* B, int ldb, float* C, int ldc, const float* bias,
-                                     float* colstat_ws, const uint32_t* a_exact_flag, void* stream) {
+                                     float* colstat_ws, const uint32_t* a_exact_flag, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !A16 || !B || !C || lda < K || lda16 < K || ldb < K || ldc < N ||
         !a_exact_flag)
         return SPARCH_EINVAL;
@@ -1227,8 +1257,10 @@ extern "C" int sparch_gemm_auto16_nt(int M, int N, int K, const float* A, int ld
 extern "C" int sparch_gemm_auto16_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                      const uint16_t* B16, int ldb16, float* C, int ldc, int zero_diag,
                                      int accumulate, const uint32_t* b_exact_flag, void* ws, size_t ws_bytes,
-                                     void* stream) {
+                                     void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !B16 || !C || lda < M || ldb < N || ldb16 < N || ldc < N ||
         !b_exact_flag)
         return SPARCH_EINVAL;
@@ -1273,7 +1305,9 @@ extern "C" int sparch_gemm_prof_read(unsigned long long* host_out, int reset) {
 }
 #endif
 
-extern "C" size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K) {
+extern "C" size_t sparch_gemm_spike_tn_workspace_bytes(int M, int N, int K, int precision) {
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return 0;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int s0 = choose_splits<0>(M, N, K), s1 = choose_splits<1>(M, N, K), s2 = choose_splits<2>(M, N, K);
     const int smax = s0 > s1 ? (s0 > s2 ? s0 : s2) : (s1 > s2 ? s1 : s2);

@@ -1655,8 +1655,10 @@ extern "C" size_t sparch_vpack_bytes(int H) {
     return (size_t)cdiv(H, CT) * (4 * kgw) * 2 * 3 * 64 * sizeof(u32x4);
 }
 
-extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked, void* stream) {
+extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, float* vmasked, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     const int kgw = pick_kgw(H);
     if (H <= 0 || kgw == 0 || !V || !vpack) return SPARCH_EINVAL;
     if (!aligned16(vpack)) return SPARCH_EALIGN;
@@ -1674,8 +1676,10 @@ extern "C" int sparch_vpack(int H, const float* V, int transpose, float* vpack, 
     return SPARCH_OK;
 }
 
-extern "C" int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream) {
+extern "C" int sparch_vpack_both(int H, const float* V, float* vpack_fwd, float* vpack_bwd, float* vmasked, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     const int kgw = pick_kgw(H);
     if (H <= 0 || kgw == 0 || !V || !vpack_fwd || !vpack_bwd) return SPARCH_EINVAL;
     if (!aligned16(vpack_fwd) || !aligned16(vpack_bwd)) return SPARCH_EALIGN;
@@ -1719,8 +1723,10 @@ extern "C" int sparch_rec_cell_fwd(int kind, int B, int dirs, int T, int H, cons
                                    const float* w0, const float* s0, float theta, float p_drop,
                                    uint64_t seed, float* s_out, uint16_t* s16_out, void* u_save, void* w_save,
                                    int save_bf16, uint32_t* spike_count, void* chan, size_t chan_bytes,
-                                   uint32_t* status, int steps_per_launch, void* stream) {
+                                   uint32_t* status, int steps_per_launch, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     // bf16 saved states cannot carry the exact state from one launch of a chunked forward to the next
     if (save_bf16 && steps_per_launch < T) return SPARCH_EINVAL;
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;
@@ -1751,8 +1757,10 @@ extern "C" int sparch_rec_cell_bwd(int kind, int B, int dirs, int T, int H, cons
                                    uint64_t seed, float* dWx, uint16_t* s_prev16, float* dparam_ws,
                                    const float* bn_x, const float* bn_mean, const float* bn_invstd,
                                    void* chan, size_t chan_bytes, uint32_t* status,
-                                   int steps_per_launch, void* stream) {
+                                   int steps_per_launch, void* stream, int precision) {
     SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
     if (bn_x && (!bn_mean || !bn_invstd || !aligned16(bn_x) || !aligned16(bn_mean) || !aligned16(bn_invstd)))
         return SPARCH_EINVAL;
     if (kind != SPARCH_KIND_RLIF && kind != SPARCH_KIND_RADLIF) return SPARCH_EINVAL;

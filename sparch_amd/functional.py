@@ -46,18 +46,28 @@ SAVE_BF16 = os.environ.get("SPARCH_SAVE_DTYPE", "fp32").lower() == "bf16"
 COMPUTE_DTYPES = {"fp32": 0, "bf16": 1}
 
 
+_precision = 0  # what this module passes as the `precision` argument of every matrix-product call (the C library
+#                keeps no such state since ABI v5: include/sparch_hip.h)
+
+
 def set_compute_dtype(name):
-    """Select the operand precision of the library's matrix products; returns the previous setting's name."""
+    """Select the operand precision this module asks of the library's matrix products; returns the previous
+    setting's name."""
+    global _precision
     name = {"float32": "fp32", "f32": "fp32", "bfloat16": "bf16"}.get(str(name).lower(), str(name).lower())
     if name not in COMPUTE_DTYPES:
         raise ValueError(f"compute dtype must be one of {sorted(COMPUTE_DTYPES)}, got {name!r}")
     prev = compute_dtype()
-    check(lib.sparch_set_operand_precision(COMPUTE_DTYPES[name]), "sparch_set_operand_precision")
+    _precision = COMPUTE_DTYPES[name]
     return prev
 
 
 def compute_dtype():
-    return "bf16" if lib.sparch_get_operand_precision() == 1 else "fp32"
+    return "bf16" if _precision == 1 else "fp32"
+
+
+def _prec():
+    return _precision
 
 
 if os.environ.get("SPARCH_COMPUTE_DTYPE"):
@@ -353,30 +363,31 @@ def gemm_nt(A, B, bias=None, colstat=False, spike_scale=None, a_exact_flag=None,
     if spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16 and b_planes is not None:
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike16_nt_wp(M, N, K, ptr(a16), a16.stride(0), float(spike_scale), ptr(B),
-                                            ptr(b_planes), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream()),
+                                            ptr(b_planes), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream(), _prec()),
               "sparch_gemm_spike16_nt_wp")
     elif spike_scale is not None and USE_SPIKE_GEMM and a16 is not None and USE_SPIKE16:
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike16_nt(M, N, K, ptr(a16), a16.stride(0), float(spike_scale), ptr(B), B.stride(0),
-                                         ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike16_nt")
+                                         ptr(C), N, ptr(bias), ptr(ws), _stream(), _prec()), "sparch_gemm_spike16_nt")
     elif spike_scale is not None and USE_SPIKE_GEMM:
         tok = timer.start(f"gemm_spike_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike_nt(M, N, K, ptr(A), A.stride(0), float(spike_scale), ptr(B), B.stride(0),
-                                       ptr(C), N, ptr(bias), ptr(ws), _stream()), "sparch_gemm_spike_nt")
+                                       ptr(C), N, ptr(bias), ptr(ws), _stream(), _prec()), "sparch_gemm_spike_nt")
     elif a_exact_flag is not None and a_plane is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
         tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")  # a_plane: plane_bf16_exact(A)[0], read when the flag is 1
         check(lib.sparch_gemm_auto16_nt(M, N, K, ptr(A), A.stride(0) or K, ptr(a_plane), a_plane.stride(0), ptr(B),
-                                        B.stride(0), ptr(C), N, ptr(bias), ptr(ws), ptr(a_exact_flag), _stream()),
+                                        B.stride(0), ptr(C), N, ptr(bias), ptr(ws), ptr(a_exact_flag), _stream(), _prec()),
               "sparch_gemm_auto16_nt")
     elif a_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
         tok = timer.start(f"gemm_auto_nt[{M}x{N}x{K}]")
         check(lib.sparch_gemm_auto_nt(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias),
-                                      ptr(ws), ptr(a_exact_flag), _stream()), "sparch_gemm_auto_nt")
+                                      ptr(ws), ptr(a_exact_flag), _stream(), _prec()), "sparch_gemm_auto_nt")
     else:
-        fn = lib.sparch_gemm6_nt if DENSE_GEMM == "split6" else lib.sparch_gemm_nt
+        split6 = DENSE_GEMM == "split6"  # (the fp32-input MFMA kernels of gemm.hip have one precision)
+        fn = lib.sparch_gemm6_nt if split6 else lib.sparch_gemm_nt
         tok = timer.start(f"gemm_nt[{M}x{N}x{K}]")
-        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream()),
-              "sparch_gemm_nt")
+        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(bias), ptr(ws), _stream(),
+                 *((_prec(),) if split6 else ())), "sparch_gemm_nt")
     timer.stop(tok)
     return C, ws
 
@@ -389,10 +400,12 @@ def gemm_nn(A, B, b_planes=None):
     tok = timer.start(f"gemm_nn[{M}x{N}x{K}]")
     if b_planes is not None and DENSE_GEMM == "split6":
         check(lib.sparch_gemm6_nn_wp(M, N, K, ptr(A), A.stride(0), ptr(B), ptr(b_planes), B.stride(0), ptr(C), N,
-                                     _stream()), "sparch_gemm6_nn_wp")
+                                     _stream(), _prec()), "sparch_gemm6_nn_wp")
     else:
-        fn = lib.sparch_gemm6_nn if DENSE_GEMM == "split6" else lib.sparch_gemm_nn
-        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream()), "sparch_gemm_nn")
+        split6 = DENSE_GEMM == "split6"
+        fn = lib.sparch_gemm6_nn if split6 else lib.sparch_gemm_nn
+        check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, _stream(), *((_prec(),) if split6 else ())),
+              "sparch_gemm_nn")
     timer.stop(tok)
     return C
 
@@ -410,43 +423,44 @@ def gemm_tn(A, B, zero_diag=False, spike_side=None, spike_scale=1.0, out=None, b
     if spike16 and not (spike_side is not None and USE_SPIKE_GEMM):
         raise RuntimeError("internal: a bf16 spike plane needs the spike GEMM path")
     if spike_side is not None and USE_SPIKE_GEMM and spike16:
-        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K, _prec())
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_spike_tn[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
                                          float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
-                                         ptr(ws), nbytes, _stream()), "sparch_gemm_spike16_tn")
+                                         ptr(ws), nbytes, _stream(), _prec()), "sparch_gemm_spike16_tn")
     elif spike_side is not None and USE_SPIKE_GEMM:
-        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K, _prec())
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_spike_tn[{M}x{N}x{K}]")
         check(lib.sparch_gemm_spike_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), int(spike_side),
                                        float(spike_scale), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
-                                       ptr(ws), nbytes, _stream()), "sparch_gemm_spike_tn")
+                                       ptr(ws), nbytes, _stream(), _prec()), "sparch_gemm_spike_tn")
     elif b_exact_flag is not None and b_plane is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
-        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, (N + 7) // 8 * 8, K)  # slabs at the plane's padded width
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, (N + 7) // 8 * 8, K, _prec())  # slabs at the plane's padded width
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
         check(lib.sparch_gemm_auto16_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0) or N, ptr(b_plane),
                                         b_plane.stride(0), ptr(C), C.stride(0), int(zero_diag), int(accumulate),
-                                        ptr(b_exact_flag), ptr(ws), nbytes, _stream()), "sparch_gemm_auto16_tn")
+                                        ptr(b_exact_flag), ptr(ws), nbytes, _stream(), _prec()), "sparch_gemm_auto16_tn")
     elif b_exact_flag is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6":
-        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K)
+        nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K, _prec())
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         tok = timer.start(f"gemm_auto_tn[{M}x{N}x{K}]")
         check(lib.sparch_gemm_auto_tn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0),
                                       int(zero_diag), int(accumulate), ptr(b_exact_flag), ptr(ws), nbytes,
-                                      _stream()), "sparch_gemm_auto_tn")
+                                      _stream(), _prec()), "sparch_gemm_auto_tn")
     else:
         if spike_side is not None and spike_scale != 1.0:
             raise RuntimeError("internal: fp32 gemm_tn fallback expects unscaled operands")
         split6 = DENSE_GEMM == "split6"
-        nbytes = (lib.sparch_gemm_spike_tn_workspace_bytes if split6 else lib.sparch_gemm_tn_workspace_bytes)(M, N, K)
+        nbytes = (lib.sparch_gemm_spike_tn_workspace_bytes(M, N, K, _prec()) if split6
+                  else lib.sparch_gemm_tn_workspace_bytes(M, N, K))
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
         fn = lib.sparch_gemm6_tn if split6 else lib.sparch_gemm_tn
         tok = timer.start(f"gemm_tn[{M}x{N}x{K}]")
         check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(zero_diag),
-                 int(accumulate), ptr(ws), nbytes, _stream()), "sparch_gemm_tn")
+                 int(accumulate), ptr(ws), nbytes, _stream(), *((_prec(),) if split6 else ())), "sparch_gemm_tn")
     timer.stop(tok)
     return C
 
@@ -643,7 +657,7 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
         vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
         vpack_t = torch.empty_like(vpack)
         vmask = torch.empty(H, H, dtype=torch.float32, device=dev)
-        check(lib.sparch_vpack_both(H, ptr(V), ptr(vpack), ptr(vpack_t), ptr(vmask), _stream()), "sparch_vpack_both")
+        check(lib.sparch_vpack_both(H, ptr(V), ptr(vpack), ptr(vpack_t), ptr(vmask), _stream(), _prec()), "sparch_vpack_both")
         # t = 0 drive: s0 is uniform noise, not binary (snns.py:559/702): a (B', H, H) dense product, split-K so
         # that its 16 output tiles become a full grid (38 -> ~15 us at B' = 256, H = 1024)
         rec0 = _gemm_small(s0, vmask, nn=True)
@@ -655,7 +669,7 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
                                           ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")), ptr(vpack),
                                           ptr(rec0), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(s_out),
                                           ptr(s16), ptr(u_save), ptr(w_save), int(save16), ptr(count), ptr(chan),
-                                          nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_fwd")
+                                          nbytes, ptr(status_word(dev)), L, _stream(), _prec()), "sparch_rec_cell_fwd")
         timer.stop(tok)
         return s_out, count, (u_save, w_save, vpack_t), s16
     return s_out, count, (u_save, w_save), s16
@@ -720,7 +734,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                 vpack_t = vpack_fwd_made
             else:
                 vpack_t = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-                check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream()), "sparch_vpack")
+                check(lib.sparch_vpack(H, ptr(V), 1, ptr(vpack_t), None, _stream(), _prec()), "sparch_vpack")
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             L = steps_per_launch if steps_per_launch is not None else rec_steps_per_launch(T)
@@ -730,7 +744,7 @@ def cell_backward(kind, g_out, g_rate, p, u0, w0, s0, saved, *, B, dirs, T, H, t
                                               int(save16), ptr(p["alpha"]), ptr(p.get("beta")), ptr(p.get("a")), ptr(p.get("b")),
                                               ptr(vpack_t), ptr(u0), ptr(w0), ptr(s0), theta, p_drop, seed, ptr(dWx),
                                               ptr(s_prev), ptr(ws), ptr(bn_x), ptr(bn_mean), ptr(bn_invstd), ptr(chan),
-                                              nbytes, ptr(status_word(dev)), L, _stream()), "sparch_rec_cell_bwd")
+                                              nbytes, ptr(status_word(dev)), L, _stream(), _prec()), "sparch_rec_cell_bwd")
             timer.stop(tok)
         # dV = sum_t s_{t-1}^T (1-alpha) du_t with the diagonal zeroed (mask at snns.py:566/712):
         # binary rows t >= 1 on the exact bf16-split path, plus the t = 0 term with the non-binary s0
@@ -1201,7 +1215,7 @@ class RNNLayerFn(torch.autograd.Function):
             timer.stop(tok)
         else:
             vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # y V^T, dense
+            check(lib.sparch_vpack(H, ptr(V), 1 | 2, ptr(vpack), None, _stream(), _prec()), "sparch_vpack")   # y V^T, dense
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_fwd[RNN]")
@@ -1239,7 +1253,7 @@ class RNNLayerFn(torch.autograd.Function):
             timer.stop(tok)
         else:
             vpack = torch.empty(lib.sparch_vpack_bytes(H) // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream()), "sparch_vpack")   # dpre V, dense
+            check(lib.sparch_vpack(H, ptr(V), 0 | 2, ptr(vpack), None, _stream(), _prec()), "sparch_vpack")   # dpre V, dense
             nbytes = lib.sparch_rec_chan_bytes(Bp, T, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ann_rec_bwd[RNN]")
@@ -1269,10 +1283,10 @@ def _gemm_small(A, B, nn):
     M, K = A.shape
     N = B.shape[1] if nn else B.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    nbytes = lib.sparch_gemm6_splitk_workspace_bytes(M, N, K)
+    nbytes = lib.sparch_gemm6_splitk_workspace_bytes(M, N, K, _prec())
     ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=A.device)
     fn = lib.sparch_gemm6_nn_splitk if nn else lib.sparch_gemm6_nt_splitk
-    check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(ws), nbytes, _stream()),
+    check(fn(M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), N, ptr(ws), nbytes, _stream(), _prec()),
           "sparch_gemm6_splitk")
     return C
 
@@ -1333,7 +1347,7 @@ class GatedLayerFn(torch.autograd.Function):
             vg = torch.empty(lib.sparch_gru_vpack_bytes(H, 0, 0) // 4, dtype=torch.float32, device=dev)
             vc = torch.empty(lib.sparch_gru_vpack_bytes(H, 0, 1) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_gru_vpack(H, ptr(P["z"]["V"]), ptr(P["r"]["V"]), ptr(P["c"]["V"]), 0, ptr(vg), ptr(vc),
-                                       _stream()), "sparch_gru_vpack")
+                                       _stream(), _prec()), "sparch_gru_vpack")
             nbytes = lib.sparch_gru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("gru_fwd")
@@ -1348,7 +1362,7 @@ class GatedLayerFn(torch.autograd.Function):
         elif persistent:
             # the whole time loop in one persistent launch per row-tile group (gatedcell.hip)
             vp = torch.empty(lib.sparch_ligru_vpack_bytes(H, 0) // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_ligru_vpack(H, ptr(P["z"]["V"]), ptr(P["c"]["V"]), 0, ptr(vp), _stream()), "sparch_ligru_vpack")
+            check(lib.sparch_ligru_vpack(H, ptr(P["z"]["V"]), ptr(P["c"]["V"]), 0, ptr(vp), _stream(), _prec()), "sparch_ligru_vpack")
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             tok = timer.start("ligru_fwd")
@@ -1405,7 +1419,7 @@ class GatedLayerFn(torch.autograd.Function):
             vg = torch.empty(lib.sparch_gru_vpack_bytes(H, 1, 0) // 4, dtype=torch.float32, device=dev)
             vc = torch.empty(lib.sparch_gru_vpack_bytes(H, 1, 1) // 4, dtype=torch.float32, device=dev)
             check(lib.sparch_gru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["r"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vg), ptr(vc),
-                                       _stream()), "sparch_gru_vpack")
+                                       _stream(), _prec()), "sparch_gru_vpack")
             nbytes = lib.sparch_gru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)
@@ -1418,7 +1432,7 @@ class GatedLayerFn(torch.autograd.Function):
             timer.stop(tok)
         elif kind == "LiGRU" and ligru_persistent_ok(H):
             vpb = torch.empty(lib.sparch_ligru_vpack_bytes(H, 1) // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_ligru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vpb), _stream()), "sparch_ligru_vpack")
+            check(lib.sparch_ligru_vpack(H, ptr(Pm["z"]["V"]), ptr(Pm["c"]["V"]), 1, ptr(vpb), _stream(), _prec()), "sparch_ligru_vpack")
             nbytes = lib.sparch_ligru_chan_bytes(Bp, H)
             chan = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)  # (ceil: the byte count need not be a multiple of 8)
             carry = new(Bp, H)

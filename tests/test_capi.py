@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from sparch_amd import _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,20 +61,23 @@ def test_argument_validation_returns_codes_without_launching():
                                1.0, 0.0, 0, 16, None, None, None, 0, None, None) == -1  # kind RLIF on non-recurrent entry
 
 
-def test_operand_precision_switch_is_host_state():
-    """sparch_set_operand_precision (the bf16 operand mode, BASELINE configs[4]): fp32-exact by default, unknown
-    modes rejected, and the Python wrapper maps the names (no GPU involved: the switch only selects which kernel
-    instantiation the next launch takes)."""
+def test_operand_precision_is_a_per_call_argument():
+    """ABI v5: the library keeps no precision state (rounds 1-2: a process-wide sparch_set_operand_precision).  Every
+    entry point that multiplies takes `precision` as its last argument; an unknown value is SPARCH_EINVAL before
+    anything is launched (0 bytes for the workspace queries); the Python module passes its own setting per call."""
     from sparch_amd import functional as Fn
     lib = _capi.lib
-    assert lib.sparch_get_operand_precision() == 0 and Fn.compute_dtype() == "fp32"
-    assert lib.sparch_set_operand_precision(7) == -1 and lib.sparch_get_operand_precision() == 0
+    assert not hasattr(lib, "sparch_set_operand_precision") or "sparch_set_operand_precision" not in _capi.PROTOTYPES
+    assert Fn.compute_dtype() == "fp32" and Fn._prec() == 0
+    assert lib.sparch_gemm_spike_tn_workspace_bytes(128, 128, 4096, 0) > 0
+    assert lib.sparch_gemm_spike_tn_workspace_bytes(128, 128, 4096, 1) > 0
+    assert lib.sparch_gemm_spike_tn_workspace_bytes(128, 128, 4096, 7) == 0
+    assert lib.sparch_gemm6_nn(4, 4, 4, None, 4, None, 4, None, 4, None, 7) == -1
+    assert lib.sparch_vpack(64, None, 0, None, None, None, 5) == -1
+    prev = Fn.set_compute_dtype("bf16")
     try:
-        assert Fn.set_compute_dtype("bfloat16") == "fp32" and Fn.compute_dtype() == "bf16"
-        assert lib.sparch_get_operand_precision() == 1
-        assert Fn.set_compute_dtype("fp32") == "bf16"
-        import pytest
+        assert prev == "fp32" and Fn.compute_dtype() == "bf16" and Fn._prec() == 1
         with pytest.raises(ValueError):
             Fn.set_compute_dtype("fp8")
     finally:
-        lib.sparch_set_operand_precision(0)
+        Fn.set_compute_dtype("fp32")
