@@ -542,6 +542,24 @@ int sparch_adam_step(int n_tensors, float* const* params, const float* const* gr
                      float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                      void* stream);
 
+/* ---- G1/G2, round 3: the gradient of a BatchNorm'd projection as bf16 planes, made ONCE.
+ * sparch_bn_bwd_apply_planes = sparch_bn_bwd_apply (dx = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M)) writing dx as
+ * its three exact bf16 planes (3 x M x H uint16, truncation split: dx = t1 + t2 + t3 — the split the dense GEMMs
+ * otherwise redo in every workgroup that stages a tile of dx); H % 8 == 0.  dy2 (nullable): the second direction's
+ * gradient of a bidirectional layer, added in the same pass (dy + dy2; replaces sparch_add_halves); dx (nullable):
+ * the fp32 tensor as well.  Consumers: sparch_gemm6_nn_pp (dX = dx * W: both operands as planes) and
+ * sparch_gemm_spike16_tn_ap (dW = dx^T * spikes: dense side as planes) — bit-identical to the fp32-operand entry
+ * points; where the pipelined plane kernels do not apply (small or ragged shapes) they read the fp32 operand, which
+ * may be NULL only if the caller has checked the shape (M, N >= one tile, K % 32 == 0, 16-byte rows). */
+int sparch_bn_bwd_apply_planes(int M, int H, const float* dy, const float* dy2, const float* x, const float* mean,
+                               const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
+                               uint16_t* planes, float* dx, void* stream);
+int sparch_gemm6_nn_pp(int M, int N, int K, const float* A, const uint16_t* A_planes, int lda, const float* B,
+                       const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream, int precision);
+int sparch_gemm_spike16_tn_ap(int M, int N, int K, const float* A, const uint16_t* A_planes, int lda,
+                              const uint16_t* B16, int ldb, float scale, float* C, int ldc, int zero_diag,
+                              int accumulate, void* ws, size_t ws_bytes, void* stream, int precision);
+
 /* ---- a11: the batch upload of the train step (exp.py:355-356 copies a dense fp32 batch to the device every step:
  * 179 MB at the headline shape).  counts (M,K) uint8 = the same binned spike counts (spiking_datasets.py:71-78) at
  * one byte per element; the call expands them into the bf16 plane the first layer's GEMMs read — (M, ldp) uint16

@@ -120,6 +120,10 @@ PROTOTYPES = {
     "sparch_gru_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_float, c_uint64, P, P, P, P, P, P,
                                P, c_size_t, P, c_int, P]),
     "sparch_gate_step": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, c_uint64, P]),
+    "sparch_bn_bwd_apply_planes": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    "sparch_gemm6_nn_pp": (c_int, [c_int, c_int, c_int, P, P, c_int, P, P, c_int, P, c_int, P, c_int]),
+    "sparch_gemm_spike16_tn_ap": (c_int, [c_int, c_int, c_int, P, P, c_int, P, c_int, c_float, P, c_int, c_int, c_int,
+                                          P, c_size_t, P, c_int]),
     "sparch_expand_counts_u8": (c_int, [ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P]),
     "sparch_ce_loss": (c_int, [c_int, c_int, P, P, P, P, P]),
     "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),

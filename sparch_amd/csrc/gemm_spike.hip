@@ -90,6 +90,10 @@ struct SArgs {
     // Bp + p * bp_stride (elements), same row layout and ldb as B.  Weight matrices are split ONCE per step
     // instead of once per workgroup that stages them (250 M-tiles re-converted the same W tile).
     const unsigned short* Bp; size_t bp_stride;
+    // APRE kernels (round 3): the dense A operand pre-split likewise — the gradient of a BatchNorm'd projection,
+    // which its producer (sparch_bn_bwd_apply_planes) writes as planes ONCE instead of every workgroup of the dX and
+    // dW products re-converting the tiles it stages (8 column tiles each).  Plane p at Ap + p * ap_stride, A's layout.
+    const unsigned short* Ap; size_t ap_stride;
     int n_splits;  // K ranges (the grid walks tiles x n_splits work items)
 };
 
@@ -354,10 +358,11 @@ constexpr int stage_elems() {  // bf16 elements of one LDS stage (all planes of 
 // !FAST: general shapes (small or unaligned operands): bounds-checked loads, single stage, two barriers.
 // NP: planes of a dense operand — 3 = the exact split (default), 1 = the bf16 operand mode (one rounding, one
 // MFMA per product; MODE 2 then has ONE term).
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3, bool APRE = false>
 __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) void gemm_spike_kernel(SArgs g) {
     static_assert(!S16 || MODE != 2, "a bf16 plane is a spike operand");
     static_assert(!BPRE || (FAST && MODE != 1), "pre-split B: pipelined kernel, B is the dense operand");
+    static_assert(!APRE || (FAST && MODE != 0 && NP == 3), "pre-split A: pipelined exact kernel, A is the dense operand");
     static_assert(NP == 3 || (NP == 1 && !BPRE), "dense operands: three exact planes or one rounded plane");
     constexpr bool BIGT = big_tile<A_KM, B_KM, MODE, FAST, NP>();
     using S = Shape<MODE, FAST, BIGT>;
@@ -415,7 +420,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
 
     constexpr bool A16 = S16 && SPIKE_A, B16 = S16 && SPIKE_B;     // operand arrives as a bf16 plane
     constexpr int NPB1 = BN * 4 / NT;  // 16-byte pieces per thread of ONE bf16 plane of the B tile
-    constexpr int NPA = BM * (A16 ? 4 : 8) / NT, NPB = BPRE ? 3 * NPB1 : BN * (B16 ? 4 : 8) / NT;  // pieces per thread and tile
+    constexpr int NPA1 = BM * 4 / NT;  // ... of ONE bf16 plane of the A tile
+    constexpr int NPA = APRE ? 3 * NPA1 : BM * (A16 ? 4 : 8) / NT, NPB = BPRE ? 3 * NPB1 : BN * (B16 ? 4 : 8) / NT;  // pieces per thread and tile
     // FAST: two register sets, tiles in flight two K tiles ahead of the MFMAs (a load issued in phase t is
     // converted in phase t + 2; one phase of a 256 x 128 tile is ~0.8 us, less than a loaded HBM round trip)
     // (not the 256 x 256 TN kernels: their phase is twice as long and they have no registers to spare)
@@ -426,7 +432,9 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     // registers -> LDS stage at `st` (piece q of the NPA + NPB pieces a thread owns)
     auto convert_piece = [&](auto& ra, auto& rb, int q, unsigned short* st) __attribute__((always_inline)) {
         if (q < NPA) {
-            if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
+            if constexpr (APRE)  // plane q / NPA1 straight into its LDS image: no conversion
+                store_piece16<A_KM, BM, NT>(ra[q], q % NPA1, st + (q / NPA1) * PLANE_A, tid);
+            else if constexpr (A16) store_piece16<A_KM, BM, NT>(ra[q], q, st, tid);
             else if constexpr (NP == 1 && !SPIKE_A) store_piece_rne1<A_KM, BM, NT>(ra[q], q, st, tid);
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
         } else if (q < NPA + NPB) {
@@ -440,7 +448,9 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
     // global -> registers, full in-range tile at K offset k (FAST only)
     auto fetch_piece = [&](auto& ra, auto& rb, int q, int k) __attribute__((always_inline)) {
         if (q < NPA) {
-            if constexpr (A16)
+            if constexpr (APRE)
+                load_piece16<A_KM, BM, NT>(ra[q], q % NPA1, true, g.Ap + (q / NPA1) * g.ap_stride, g.lda, m0, g.M, k, k_end, 1, tid);
+            else if constexpr (A16)
                 load_piece16<A_KM, BM, NT>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
             else load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
         } else if (q < NPA + NPB) {
@@ -619,7 +629,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             __syncthreads();
         }
         const int k_tail = k_begin + nt * BK;
-        if constexpr (!BPRE)   // (pre-split B: the host launches these kernels for K % 32 == 0 only)
+        if constexpr (!BPRE && !APRE)   // (pre-split operands: the host launches these kernels for K % 32 == 0 only)
         if (k_tail < k_end) {  // K tail (< 32 deep): element-wise bounds-checked loads, zero filled
             stage_load<A_KM, BM, NT, A16>(ra, g.A, g.lda, m0, g.M, k_tail, k_end, 0, tid);
             stage_load<B_KM, BN, NT, B16>(rb, g.B, g.ldb, n0, g.N, k_tail, k_end, 0, tid);
@@ -771,7 +781,7 @@ bool fast_ok(const SArgs& g) {
            g.k_per_split >= 8 * BK;  // a short K range never fills the pipeline: general kernel, 2 workgroups per CU
 }
 
-template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3>
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool FAST, bool S16, bool BPRE = false, int NP = 3, bool APRE = false>
 int launch_variant(SArgs& g, int splits, hipStream_t st) {
     constexpr bool BIGT = big_tile<A_KM, B_KM, MODE, FAST, NP>();
     using S = Shape<MODE, FAST, BIGT>;
@@ -783,7 +793,7 @@ int launch_variant(SArgs& g, int splits, hipStream_t st) {
     const int cus = target_wgs(1);
     const int wgs = (FAST && !BIGT && persistent && work > cus) ? cus : work;
     constexpr size_t lds_bytes = (size_t)(FAST ? 2 : 1) * stage_elems<A_KM, B_KM, MODE, FAST, NP>() * sizeof(unsigned short);
-    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE, NP>;
+    auto kernel = gemm_spike_kernel<A_KM, B_KM, MODE, EPI, FAST, S16, BPRE, NP, APRE>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) { sparch_note_hip_error((int)attr); return SPARCH_ELAUNCH; }
@@ -811,6 +821,21 @@ int launch_wp(SArgs& g, int splits, hipStream_t st) {
     if (planes_ok && !sparch_operand_bf16() && fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
         return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, true>(g, splits, st);
     return launch<A_KM, B_KM, MODE, EPI, S16>(g, splits, st);
+}
+
+// ... and with A's pre-split planes (B's too where BPRE says so), under the same conditions; otherwise the ordinary
+// kernels convert A on the fly from its fp32 form, which the caller must then have supplied (g.A)
+template <bool A_KM, bool B_KM, int MODE, int EPI, bool S16, bool BPRE>
+int launch_ap(SArgs& g, int splits, hipStream_t st) {
+    const bool a_ok = g.Ap != nullptr && aligned16(g.Ap) && g.lda % 8 == 0 && (g.ap_stride % 8) == 0 &&
+                      g.k_per_split % BK == 0 && g.K % BK == 0 && (!A_KM || g.M % 8 == 0);
+    const bool b_ok = !BPRE || (g.Bp != nullptr && aligned16(g.Bp) && g.ldb % 8 == 0 && (g.bp_stride % 8) == 0 &&
+                                (!B_KM || g.N % 8 == 0));
+    if (a_ok && b_ok && !sparch_operand_bf16() && fast_ok<A_KM, B_KM, MODE, EPI, S16>(g))
+        return launch_variant<A_KM, B_KM, MODE, EPI, true, S16, BPRE, 3, true>(g, splits, st);
+    if (g.A == nullptr) return SPARCH_EINVAL;  // planes alone cannot run the general kernels
+    if constexpr (BPRE) return launch_wp<A_KM, B_KM, MODE, EPI, S16>(g, splits, st);
+    else return launch<A_KM, B_KM, MODE, EPI, S16>(g, splits, st);
 }
 
 // x -> three exact bf16 planes (truncation split, as store_piece<..., TRUNC> does on the fly)
@@ -973,6 +998,55 @@ extern "C" int sparch_gemm_spike16_tn(int M, int N, int K, const void* A, int ld
     g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
     int rc = spike_side == 0 ? launch<true, true, 0, EPI_NONE, true>(g, splits, st)
                              : launch<true, true, 1, EPI_NONE, true>(g, splits, st);
+    if (rc != SPARCH_OK) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, C, M, N, ldc, splits, zero_diag, accumulate);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+// C[M,N] = A[M,K] * B[K,N], BOTH operands given as their three exact bf16 planes (A_planes: 3 x M x lda,
+// B_planes: 3 x K x ldb); A / B themselves (fp32, same layouts) are read instead where the pipelined plane kernel
+// does not apply — A may be NULL when the caller knows it does (sparch_gemm6_nn_pp_applies).
+extern "C" int sparch_gemm6_nn_pp(int M, int N, int K, const float* A, const uint16_t* A_planes, int lda, const float* B,
+                                  const uint16_t* B_planes, int ldb, float* C, int ldc, void* stream, int precision) {
+    SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (!A && !A_planes) || !B || !C || lda < K || ldb < N || ldc < N) return SPARCH_EINVAL;
+    SArgs g{};
+    g.A = A; g.B = B; g.C = C; g.Bp = B_planes; g.bp_stride = (size_t)K * ldb;
+    g.Ap = A_planes; g.ap_stride = (size_t)M * lda;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.k_per_split = cdiv(K, BK) * BK; g.c_split_stride = 0; g.scale = 1.0f;
+    g.a_vec = (A ? aligned16(A) : true) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    return launch_ap<false, true, 2, EPI_NONE, false, true>(g, 1, (hipStream_t)stream);
+}
+
+// C[M,N] (+)= A[K,M]^T * B[K,N] with B a bf16 spike plane (as sparch_gemm_spike16_tn, spike_side = 1) and the dense A
+// given as its three exact bf16 planes (3 x K x lda); A itself (fp32) as for sparch_gemm6_nn_pp.
+extern "C" int sparch_gemm_spike16_tn_ap(int M, int N, int K, const float* A, const uint16_t* A_planes, int lda,
+                                         const uint16_t* B16, int ldb, float scale, float* C, int ldc, int zero_diag,
+                                         int accumulate, void* ws, size_t ws_bytes, void* stream, int precision) {
+    SPARCH_ENTER();
+    PrecisionScope prec_scope_(precision);
+    if (!prec_scope_.ok) return SPARCH_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (!A && !A_planes) || !B16 || !C || lda < M || ldb < N || ldc < N) return SPARCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = choose_splits<1>(M, N, K);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return SPARCH_EWORKSPACE;
+    SArgs g{};
+    g.A = A; g.B = reinterpret_cast<const float*>(B16);
+    g.Ap = A_planes; g.ap_stride = (size_t)K * lda;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.scale = scale;
+    g.a_vec = (A ? aligned16(A) : true) && (lda % 4 == 0);
+    g.b_vec = aligned16(B16) && (ldb % 8 == 0);
+    g.C = (float*)ws; g.ldc = N; g.c_split_stride = (size_t)M * N;
+    g.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+    int rc = launch_ap<true, true, 1, EPI_NONE, true, false>(g, splits, st);
     if (rc != SPARCH_OK) return rc;
     const size_t total = (size_t)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

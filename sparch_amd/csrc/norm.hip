@@ -217,6 +217,81 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int H, float i
     }
 }
 
+// The same pass writing dx as its three exact bf16 planes (x = t1 + t2 + t3, the truncation split the split GEMMs
+// otherwise redo in every workgroup that stages a tile of dx): 8 columns per thread, 16-byte plane stores.  dy2
+// (nullable): the second direction's gradient of a bidirectional layer, added here (dy = dy + dy2) instead of by
+// a separate pass (sparch_add_halves).  dx (nullable): the fp32 tensor as well.
+typedef unsigned bna_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(int M, int H, float invM, const float* __restrict__ dy,
+                                                                  const float* __restrict__ dy2,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ dgamma,
+                                                                  const float* __restrict__ dbeta,
+                                                                  unsigned short* __restrict__ planes,
+                                                                  float* __restrict__ dx) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (c >= H) return;
+    float k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float is = invstd[c + e], gi = gamma[c + e] * is;
+        const float t = is * (dgamma[c + e] * invM);
+        k1[e] = gi;
+        k2[e] = -(gi * t);
+        k3[e] = gi * (mean[c + e] * t - dbeta[c + e] * invM);
+    }
+    const size_t plane = (size_t)M * H;
+    constexpr int UR = 2;
+    for (int r = blockIdx.y * UR; r < M; r += gridDim.y * UR) {
+        f32x4 d[UR][2], xv[UR][2], d2[UR][2];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const size_t o = (size_t)min(r + u, M - 1) * H + c;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                d[u][h] = *reinterpret_cast<const f32x4*>(dy + o + 4 * h);
+                xv[u][h] = *reinterpret_cast<const f32x4*>(x + o + 4 * h);
+                if (dy2) d2[u][h] = *reinterpret_cast<const f32x4*>(dy2 + o + 4 * h);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            if (r + u >= M) break;
+            const size_t o = (size_t)(r + u) * H + c;
+            float out[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float g = d[u][e >> 2][e & 3];
+                if (dy2) g = g + d2[u][e >> 2][e & 3];
+                out[e] = k1[e] * g + k2[e] * xv[u][e >> 2][e & 3] + k3[e];
+            }
+            bna_u32x4 w1, w2, w3;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const unsigned x0 = __float_as_uint(out[2 * pr]), x1 = __float_as_uint(out[2 * pr + 1]);
+                const float r0 = out[2 * pr] - __uint_as_float(x0 & 0xFFFF0000u);
+                const float r1 = out[2 * pr + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+                const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+                const float q0 = r0 - __uint_as_float(y0 & 0xFFFF0000u);
+                const float q1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+                w1[pr] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                w2[pr] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+                w3[pr] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            }
+            *reinterpret_cast<bna_u32x4*>(planes + o) = w1;
+            *reinterpret_cast<bna_u32x4*>(planes + plane + o) = w2;
+            *reinterpret_cast<bna_u32x4*>(planes + 2 * plane + o) = w3;
+            if (dx) {
+                *reinterpret_cast<f32x4*>(dx + o) = f32x4{out[0], out[1], out[2], out[3]};
+                *reinterpret_cast<f32x4*>(dx + o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+            }
+        }
+    }
+}
+
 __global__ void bn_bwd_apply_scalar_kernel(size_t n, int H, float invM, const float* __restrict__ dy,
                                            const float* __restrict__ x, const float* __restrict__ mean,
                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -374,6 +449,24 @@ extern "C" int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x
         hipLaunchKernelGGL(bn_bwd_apply_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
                            H, 1.0f / (float)M, dy, x, mean, invstd, gamma, dgamma, dbeta, dx);
     }
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
+
+extern "C" int sparch_bn_bwd_apply_planes(int M, int H, const float* dy, const float* dy2, const float* x,
+                                          const float* mean, const float* invstd, const float* gamma,
+                                          const float* dgamma, const float* dbeta, uint16_t* planes, float* dx,
+                                          void* stream) {
+    SPARCH_ENTER();
+    if (M <= 0 || H <= 0 || H % 8 != 0 || !dy || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !planes)
+        return SPARCH_EINVAL;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(planes) || (dy2 && !aligned16(dy2)) || (dx && !aligned16(dx)))
+        return SPARCH_EALIGN;
+    const int bx = cdiv(H / 8, 256);
+    const int groups = cdiv(M, 2);
+    const int by = groups < 4096 / bx ? groups : 4096 / bx;
+    hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(bx, by), dim3(256), 0, (hipStream_t)stream, M, H,
+                       1.0f / (float)M, dy, dy2, x, mean, invstd, gamma, dgamma, dbeta, planes, dx);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

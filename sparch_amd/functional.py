@@ -27,6 +27,15 @@ PRESPLIT_NT = os.environ.get("SPARCH_PRESPLIT_NT", "0") == "1"  # ... also for t
 # Dense GEMMs: "split6" = exact 6-term bf16 split on the bf16 MFMA (default), "fp32" = fp32-input MFMA.
 DENSE_GEMM = os.environ.get("SPARCH_DENSE_GEMM", "split6")
 
+# The gradient of a BatchNorm'd projection may leave the BatchNorm pass as its three exact bf16 planes (made once) so
+# that the dX / dW products read planes instead of re-splitting the fp32 tensor in every workgroup that stages a tile
+# of it; results are bit-identical either way.  Measured (round 3, A/B in one call): at the headline shape the
+# products do not get faster for it (dX 0.69 -> 0.67 ms, dW unchanged: conversion VALU is NOT what bounds them) and
+# the pass writes half as much again (0.125 -> 0.165 ms): 6.58 -> 6.63 ms per step.  For a BIDIRECTIONAL layer the
+# same pass also adds the two directions' gradients (no separate sparch_add_halves pass): cfg5 76.1 -> 74.7 ms.
+# Hence "auto" = bidirectional layers only; SPARCH_DX_PLANES=1 / 0 forces it on / off.
+USE_DX_PLANES = {"1": True, "0": False}.get(os.environ.get("SPARCH_DX_PLANES", "auto"), "auto")
+
 # BatchNorm backward's column sums (dbeta, dgamma) come out of the cell's backward kernel instead of a
 # separate pass over dy and x (SPARCH_FUSE_BN_SUMS=0: the separate sparch_bn_bwd_reduce pass, for comparison).
 FUSE_BN_SUMS = os.environ.get("SPARCH_FUSE_BN_SUMS", "1") != "0"
@@ -527,9 +536,12 @@ class _Norm:
         return Wx_raw, None, None, None
 
     @staticmethod
-    def backward(mode, dy, Wx_raw, weight, saved, training, sums=None):
+    def backward(mode, dy, Wx_raw, weight, saved, training, sums=None, planes=False, dy2=None, keep_fp32=True):
         """dy (M,H) grad wrt the normalised projection -> (dx_raw, dweight, dbias). May overwrite dy.
-        sums = (dbeta, dgamma) when the cell's backward kernel already produced BatchNorm's column sums."""
+        sums = (dbeta, dgamma) when the cell's backward kernel already produced BatchNorm's column sums.
+        planes=True (batchnorm, H % 8 == 0): returns (dx_raw or None, dweight, dbias, dx_planes) with dx_planes the
+        (3, M, H) bf16 planes of dx_raw; keep_fp32=False skips the fp32 tensor (dx_raw is None).  dy2: the second
+        direction's gradient of a bidirectional layer, added in the same pass (dy + dy2)."""
         M, H = dy.shape
         dev = dy.device
         if mode == "batchnorm":
@@ -555,6 +567,15 @@ class _Norm:
             else:  # fixed statistics: dx = dy * gamma * invstd, i.e. the batch-coupling terms vanish
                 cg = torch.zeros(H, dtype=torch.float32, device=dev)
                 cb = cg
+            if planes:
+                dxp = torch.empty(3, M, H, dtype=torch.bfloat16, device=dev)
+                dx_out = dy if keep_fp32 else None
+                tok = timer.start(f"bn_bwd_apply_planes[{M}x{H}]")
+                check(lib.sparch_bn_bwd_apply_planes(M, H, ptr(dy), ptr(dy2), ptr(Wx_raw), ptr(mean), ptr(invstd),
+                                                     ptr(weight), ptr(cg), ptr(cb), ptr(dxp), ptr(dx_out), _stream()),
+                      "sparch_bn_bwd_apply_planes")
+                timer.stop(tok)
+                return dx_out, dgamma, dbeta, dxp
             check(lib.sparch_bn_bwd_apply(M, H, ptr(dy), ptr(Wx_raw), ptr(mean), ptr(invstd), ptr(weight),
                                           ptr(cg), ptr(cb), ptr(dy), _stream()), "sparch_bn_bwd_apply")
             return dy, dgamma, dbeta
@@ -858,23 +879,53 @@ class SpikingLayerFn(torch.autograd.Function):
         dWx, pg = cell_backward(kind, g_s, g_rate, p, u0, w0, s0, ctx.cell_saved, B=B, dirs=dirs, T=T, H=H,
                                 theta=cfg["theta"], p_drop=cfg["p_drop"], seed=cfg["seed"], bn=bn)
         ctx.cell_saved = None
-        if dirs == 2:  # both directions share the projection rows (snns.py:252-254)
-            dy = torch.empty(B, T, H, dtype=torch.float32, device=dev)
-            check(lib.sparch_add_halves(M * H, ptr(dWx), ptr(dy), _stream()), "sparch_add_halves")
-        else:
-            dy = dWx
-        dy = dy.view(M, H)
-        dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"], sums=pg.get("bn_sums"))
         in_scale = cfg.get("in_spike_scale")
         x16 = cfg.get("in_spike16") if (in_scale is not None and USE_SPIKE16) else None
-        if x16 is not None and USE_SPIKE_GEMM:
-            dW = gemm_tn(dx_raw, x16.view(M, K), spike_side=1, spike_scale=in_scale, spike16=True)
-        elif in_scale is not None and USE_SPIKE_GEMM:
-            dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
+        # dx as bf16 planes (made once by the BatchNorm pass) for the dW and dX products: a hidden layer fed by a spike
+        # plane, exact mode, shapes the pipelined plane kernels take (whole tiles, 32-deep K tiles)
+        use_planes = ((USE_DX_PLANES is True or (USE_DX_PLANES == "auto" and dirs == 2))
+                      and norm == "batchnorm" and x16 is not None and USE_SPIKE_GEMM and DENSE_GEMM == "split6"
+                      and _precision == 0 and H % 32 == 0 and K % 32 == 0 and H >= 256 and K >= 256 and M >= 256
+                      and M % 32 == 0 and (not ctx.needs_input_grad[1] or ctx.w_planes is not None))
+        need_bias = ctx.needs_input_grad[3]
+        if use_planes:
+            dy2 = dWx[B:].view(M, H) if dirs == 2 else None  # second direction: added by the same pass
+            dx_raw, dnw, dnb, dxp = _Norm.backward(norm, dWx[:B].view(M, H), Wx_raw, nw, ctx.nsaved, cfg["training"],
+                                                   sums=pg.get("bn_sums"), planes=True, dy2=dy2, keep_fp32=need_bias)
+            nbytes = lib.sparch_gemm_spike_tn_workspace_bytes(H, K, M, _prec())
+            ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=dev)
+            dW = torch.empty(H, K, dtype=torch.float32, device=dev)
+            x16m = x16.view(M, K)
+            tok = timer.start(f"gemm_spike_tn[{H}x{K}x{M}]")
+            check(lib.sparch_gemm_spike16_tn_ap(H, K, M, ptr(dx_raw), ptr(dxp), H, ptr(x16m), x16m.stride(0), float(in_scale),
+                                                ptr(dW), K, 0, 0, ptr(ws), nbytes, _stream(), _prec()),
+                  "sparch_gemm_spike16_tn_ap")
+            timer.stop(tok)
+            dWb = _colsum(dx_raw) if need_bias else None
+            dx = None
+            if ctx.needs_input_grad[1]:
+                dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+                tok = timer.start(f"gemm_nn[{M}x{K}x{H}]")
+                check(lib.sparch_gemm6_nn_pp(M, K, H, ptr(dx_raw), ptr(dxp), H, ptr(W), ptr(ctx.w_planes), K, ptr(dx), K,
+                                             _stream(), _prec()), "sparch_gemm6_nn_pp")
+                timer.stop(tok)
+                dx = dx.view(B, T, K)
         else:
-            dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag, b_plane=ctx.xplane)
-        dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
-        dx = gemm_nn(dx_raw, W, b_planes=ctx.w_planes).view(B, T, K) if ctx.needs_input_grad[1] else None
+            if dirs == 2:  # both directions share the projection rows (snns.py:252-254)
+                dy = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+                check(lib.sparch_add_halves(M * H, ptr(dWx), ptr(dy), _stream()), "sparch_add_halves")
+            else:
+                dy = dWx
+            dy = dy.view(M, H)
+            dx_raw, dnw, dnb = _Norm.backward(norm, dy, Wx_raw, nw, ctx.nsaved, cfg["training"], sums=pg.get("bn_sums"))
+            if x16 is not None and USE_SPIKE_GEMM:
+                dW = gemm_tn(dx_raw, x16.view(M, K), spike_side=1, spike_scale=in_scale, spike16=True)
+            elif in_scale is not None and USE_SPIKE_GEMM:
+                dW = gemm_tn(dx_raw, x2, spike_side=1, spike_scale=in_scale)  # (H,K) = dx_raw^T x, x spikes
+            else:
+                dW = gemm_tn(dx_raw, x2, b_exact_flag=ctx.xflag, b_plane=ctx.xplane)
+            dWb = _colsum(dx_raw) if need_bias else None
+            dx = gemm_nn(dx_raw, W, b_planes=ctx.w_planes).view(B, T, K) if ctx.needs_input_grad[1] else None
         ctx.w_planes = ctx.xplane = None
         return (None, dx, dW, dWb, dnw, dnb, pg.get("alpha"), pg.get("beta"), pg.get("a"), pg.get("b"),
                 pg.get("V"), None, None, None)

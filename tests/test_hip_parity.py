@@ -1504,6 +1504,41 @@ def test_full_size_properties(sp, neuron_type, sizes, B, T, C):
 
 # ------------------------------------------------------------------ f-2: optimizer step on the device
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,bidir,bias", [("RadLIF", False, False), ("adLIF", True, False), ("RLIF", False, True)])
+def test_dx_planes_path_is_bit_identical(sp, kind, bidir, bias, monkeypatch):
+    """The gradient of a BatchNorm'd projection as bf16 planes made once by the BatchNorm pass
+    (sparch_bn_bwd_apply_planes, with the bidirectional halves added in the same pass) and read by the dW / dX products
+    (sparch_gemm_spike16_tn_ap, sparch_gemm6_nn_pp) against the fp32-operand path of rounds 1-2 (SPARCH_DX_PLANES=0):
+    the truncation split is the same one, so every parameter gradient must be IDENTICAL bit for bit."""
+    Fn = _Fn()
+    B, T, C, sizes = 4, 64, 40, [256, 256, 10]
+    torch.manual_seed(8)
+    net = sp.SNN((B, None, C), sizes, neuron_type=kind, dropout=0.1, bidirectional=bidir, use_bias=bias).to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(B, T, C, generator=g) < 0.2).float().to(DEV)
+    y = torch.randint(0, sizes[-1], (B,), generator=g).to(DEV)
+    res = []
+    for planes in (True, False):
+        monkeypatch.setattr(Fn, "USE_DX_PLANES", planes)
+        for lay in net.snn:
+            lay._calls = 0
+        net.zero_grad()
+        torch.manual_seed(5)
+        Fn.timer.reset()
+        Fn.timer.enabled = True
+        out, rates = net(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        Fn.timer.enabled = False
+        names = set(Fn.timer.collect())
+        Fn.check_status()
+        assert any(n.startswith("bn_bwd_apply_planes") for n in names) == planes
+        res.append({k: v.grad.clone() for k, v in net.named_parameters()})
+    assert float(sum(v.abs().sum() for v in res[0].values())) > 0
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,K", [("RadLIF", 700), ("adLIF", 40), ("LIF", 33)])
 def test_input_uploaded_as_bytes_equals_the_float_batch(sp, kind, K):
     """The train step's batch as one byte per element (functional.input_from_counts; the reference moves the dense
