@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_$TAG
 rm -rf ${O}_stats ${O}_fetch ${O}_write ${O}_mfma
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > ${O}_stats.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${O}_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > ${O}_fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${O}_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > ${O}_write.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${O}_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > ${O}_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --graph off "$@" > ${O}_stats.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${O}_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph off "$@" > ${O}_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${O}_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph off "$@" > ${O}_write.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${O}_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph off "$@" > ${O}_mfma.log 2>&1
 echo "rc=$?"; du -sh ${O}_* | tail -8

@@ -59,7 +59,11 @@ def pmc(fetch_dir, write_dir, out_md, out_json, title):
         w_kb = sum(wr[k]) / len(wr[k]) if k in wr else 0.0
         table[k] = {"launches": len(fe[k]), "fetch_kb": f_kb, "write_kb": w_kb, "hbm_bytes": (2 * f_kb + w_kb) * 1024}
     order = sorted(table, key=lambda k: -table[k]["hbm_bytes"] * table[k]["launches"])
-    json.dump({k: table[k] for k in order}, open(out_json, "w"), indent=1)
+    out = {k: table[k] for k in order}
+    import os
+    # which tree the counters were collected on (bench.py quotes it beside roofline.traffic)
+    out["_meta"] = {"commit": os.environ.get("PROFILE_COMMIT"), "title": title}
+    json.dump(out, open(out_json, "w"), indent=1)
     with open(out_md, "w") as o:
         o.write(f"# {title}\n# per launch; KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                 "(gfx950: FETCH_SIZE counts wide streaming reads at 1/2)\n\n")
