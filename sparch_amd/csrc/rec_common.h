@@ -43,7 +43,7 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #define REC_BWD_XSTORE 1  /* backward: bulk stores issued one step later by the waves without pointwise state */
 #endif
 #ifndef REC_BWD_LATE_PREFETCH
-#define REC_BWD_LATE_PREFETCH 2  /* backward: where the next step's HBM inputs are requested — 0: loop top, in front of the tile loads (1.083 ms per launch); 1: behind the last tile load (1.057); 2: behind the reduction barrier, a pointwise phase and a publish ahead of the next tile loads (1.036; round 3, A/B in one call); 3: behind the publish barrier, with the rec-independent part of the reverse step moved behind the tile loop (1.097) */
+#define REC_BWD_LATE_PREFETCH 2  /* backward: where the next step's HBM inputs are requested — 0: loop top, in front of the tile loads (1.083 ms per launch); 1: behind the last tile load (1.057); 2: behind the reduction barrier, a pointwise phase and a publish ahead of the next tile loads (1.036; round 3, A/B in one call); 3: behind the publish barrier, with the rec-independent part of the reverse step moved behind the tile loop (1.097); 4: behind the publish stores, in front of the publish barrier (1.049 against 1.031 for 2 at that time) */
 #endif
 #ifndef REC_FWD_UPPER_SLEEP
 #define REC_FWD_UPPER_SLEEP 0  /* forward: s_sleep units (64 cycles) of the waves without pointwise state before they poll again */

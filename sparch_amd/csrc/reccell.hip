@@ -992,6 +992,9 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
 #endif
         }
         }
+#if REC_BWD_LATE_PREFETCH == 4
+        if (pw && t - 1 >= a.t_begin) load_step(t - 1, g_nx, up_nx, wp_nx, xr_nx);
+#endif
         PROF_STAMP(3);  // pointwise + tile store issue
 #ifndef REC_NO_PUBLISH_BARRIER
         lds_barrier();  // the non-pointwise waves start polling only once this workgroup's own tile is on its way
