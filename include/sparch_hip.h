@@ -226,11 +226,14 @@ int sparch_bn_bwd_apply(int M, int H, const float* dy, const float* x, const flo
                         const float* invstd, const float* gamma, const float* dgamma,
                         const float* dbeta, float* dx, void* stream);
 
-/* LayerNorm over H per row: y = (x-mu)*rstd*gamma + beta; saves mu, rstd (M each).    */
-int sparch_layernorm_fwd(int M, int H, const float* x, const float* gamma, const float* beta,
+/* LayerNorm per row over the leading Hn of H columns (Hn == H normally; Hn < H: columns
+ * Hn..H-1 are zero padding of a layer run at a padded width — y and dx are written 0 there
+ * and they take no part in the statistics): y = (x-mu)*rstd*gamma + beta; saves mu, rstd
+ * (M each).                                                                            */
+int sparch_layernorm_fwd(int M, int H, int Hn, const float* x, const float* gamma, const float* beta,
                          float eps, float* y, float* mu, float* rstd, void* stream);
 /* dx per row; dgamma/dbeta column sums via ws (2*ceil(M/256)*H floats).               */
-int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const float* mu,
+int sparch_layernorm_bwd(int M, int H, int Hn, const float* dy, const float* x, const float* mu,
                          const float* rstd, const float* gamma, float* dx, float* dgamma,
                          float* dbeta, void* ws, size_t ws_bytes, void* stream);
 

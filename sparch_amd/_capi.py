@@ -64,8 +64,8 @@ PROTOTYPES = {
     "sparch_bn_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sparch_bn_bwd_reduce": (c_int, [c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     "sparch_bn_bwd_apply": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P]),
-    "sparch_layernorm_fwd": (c_int, [c_int, c_int, P, P, P, c_float, P, P, P, P]),
-    "sparch_layernorm_bwd": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "sparch_layernorm_fwd": (c_int, [c_int, c_int, c_int, P, P, P, c_float, P, P, P, P]),
+    "sparch_layernorm_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sparch_cell_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P,
                                 c_float, c_float, c_uint64, P, P, P, P, c_int, P, P]),
     "sparch_cell_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P,

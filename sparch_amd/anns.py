@@ -134,20 +134,19 @@ class _HiddenANNLayer(_ANNLayer):
 
     def _cfg(self, x, dirs):
         p_drop = float(self.dropout) if self.training else 0.0
+        ln_width = self.hidden_size if (self.normalization == "layernorm" and self.hidden_size % 4) else None
         return {"normalization": self.normalization, "training": self.training, "dirs": dirs, "p_drop": p_drop,
-                "seed": self._dropout_seed(x.device) if p_drop > 0 else 0}
+                "seed": self._dropout_seed(x.device) if p_drop > 0 else 0, "ln_width": ln_width}
 
     # ---- widths that are not multiples of 4 (the kernels own 4 columns per thread; the reference takes any
     # nb_hiddens, anns.py:149-595): the layer runs zero-padded to the next multiple of 4.  A padded unit has zero
     # input weights and zero recurrent weights in both directions, so it feeds nothing; its outputs are sliced away
     # and, the padding being torch.nn.functional.pad, autograd slices the gradients back by itself.  LayerNorm
-    # normalises over the width and is therefore not paddable.
+    # normalises over the width: its kernels take the true width beside the padded one (cfg["ln_width"]) and leave
+    # the padding columns out of the statistics (output and input gradient 0 there).
     def _pad_width(self):
         H = self.hidden_size
-        H4 = (H + 3) // 4 * 4
-        if H4 != H and self.normalization == "layernorm":
-            raise ValueError("sparch_amd: non-spiking baseline layers with layernorm need hidden_size % 4 == 0")
-        return H4 - H
+        return (H + 3) // 4 * 4 - H
 
     @staticmethod
     def _padded(t, extra, square=False):

@@ -312,7 +312,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int H, const float* __restrict__ x,
+// Hn <= H: the leading Hn columns are the normalised width, columns Hn..H-1 are padding (written 0 / gradient 0)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int H, int Hn, const float* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             float* __restrict__ y, float* __restrict__ mu,
@@ -322,19 +323,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int H, const 
     if (row >= M) return;
     const float* xr = x + (size_t)row * H;
     float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / (float)H;
+    for (int c = lane; c < Hn; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)Hn;
     float v = 0.f;
-    for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; v += d * d; }
-    const float var = wave_sum(v) / (float)H;
+    for (int c = lane; c < Hn; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)Hn;
     const float rs = 1.0f / sqrtf(var + eps);
     float* yr = y + (size_t)row * H;
-    for (int c = lane; c < H; c += 64) yr[c] = (xr[c] - mean) * rs * gamma[c] + beta[c];
+    for (int c = lane; c < Hn; c += 64) yr[c] = (xr[c] - mean) * rs * gamma[c] + beta[c];
+    for (int c = Hn + lane; c < H; c += 64) yr[c] = 0.f;
     if (lane == 0) { mu[row] = mean; rstd[row] = rs; }
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = gamma*dy
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int H, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int H, int Hn, const float* __restrict__ dy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ mu,
                                                             const float* __restrict__ rstd,
@@ -347,18 +349,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int H, const 
     const float* xr = x + (size_t)row * H;
     const float* dr = dy + (size_t)row * H;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < H; c += 64) {
+    for (int c = lane; c < Hn; c += 64) {
         const float g = gamma[c] * dr[c];
         s1 += g;
         s2 += g * ((xr[c] - m) * rs);
     }
-    s1 = wave_sum(s1) / (float)H;
-    s2 = wave_sum(s2) / (float)H;
+    s1 = wave_sum(s1) / (float)Hn;
+    s2 = wave_sum(s2) / (float)Hn;
     float* o = dx + (size_t)row * H;
-    for (int c = lane; c < H; c += 64) {
+    for (int c = lane; c < Hn; c += 64) {
         const float xh = (xr[c] - m) * rs;
         o[c] = rs * (gamma[c] * dr[c] - s1 - xh * s2);
     }
+    for (int c = Hn + lane; c < H; c += 64) o[c] = 0.f;
 }
 
 // ---------------------------------------------------------------- misc elementwise
@@ -471,34 +474,35 @@ extern "C" int sparch_bn_bwd_apply_planes(int M, int H, const float* dy, const f
     return SPARCH_OK;
 }
 
-extern "C" int sparch_layernorm_fwd(int M, int H, const float* x, const float* gamma, const float* beta,
+extern "C" int sparch_layernorm_fwd(int M, int H, int Hn, const float* x, const float* gamma, const float* beta,
                                     float eps, float* y, float* mu, float* rstd, void* stream) {
     SPARCH_ENTER();
-    if (M <= 0 || H <= 0 || !x || !gamma || !beta || !y || !mu || !rstd) return SPARCH_EINVAL;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, H, x,
+    if (M <= 0 || H <= 0 || Hn <= 0 || Hn > H || !x || !gamma || !beta || !y || !mu || !rstd) return SPARCH_EINVAL;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, H, Hn, x,
                        gamma, beta, eps, y, mu, rstd);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
 
-extern "C" int sparch_layernorm_bwd(int M, int H, const float* dy, const float* x, const float* mu,
+extern "C" int sparch_layernorm_bwd(int M, int H, int Hn, const float* dy, const float* x, const float* mu,
                                     const float* rstd, const float* gamma, float* dx, float* dgamma,
                                     float* dbeta, void* ws, size_t ws_bytes, void* stream) {
     SPARCH_ENTER();
-    if (M <= 0 || H <= 0 || !dy || !x || !mu || !rstd || !gamma || !dx || !dgamma || !dbeta) return SPARCH_EINVAL;
+    if (M <= 0 || H <= 0 || Hn <= 0 || Hn > H || !dy || !x || !mu || !rstd || !gamma || !dx || !dgamma || !dbeta)
+        return SPARCH_EINVAL;
     if (!ws || ws_bytes < sparch_bn_bwd_workspace_bytes(M, H)) return SPARCH_EWORKSPACE;
     if (!aligned16(dy) || !aligned16(x)) return SPARCH_EALIGN;
     const int n_rb = cdiv(M, RB);
     hipStream_t st = (hipStream_t)stream;
-    // column sums first (dx may alias dy)
+    // column sums first (dx may alias dy); the padding columns' sums are finite and unused (x = 0, gamma = 0 there)
     hipLaunchKernelGGL(colpartial_kernel<2>, dim3(cdiv(H, 256), n_rb), dim3(256), 0, st, M, H, dy, x, mu, rstd,
                        (float*)ws, n_rb);
     SPARCH_CHECK_LAUNCH();
     hipLaunchKernelGGL(colfinish_kernel, dim3(cdiv(H, CS_COLS)), dim3(256), 0, st, H, n_rb, 2, (const float*)ws,
                        dbeta, dgamma);
     SPARCH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, M, H, dy, x, mu, rstd, gamma,
-                       dx);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, M, H, Hn, dy, x, mu, rstd,
+                       gamma, dx);
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }

@@ -502,9 +502,10 @@ class _Norm:
     (scale, shift) consumed by the cell kernel; LayerNorm materialises the normalised tensor."""
 
     @staticmethod
-    def forward(mode, Wx_raw, colstat, weight, bias, running_mean, running_var, training, dup, nbt=None):
+    def forward(mode, Wx_raw, colstat, weight, bias, running_mean, running_var, training, dup, nbt=None, ln_width=None):
         """nbt: BatchNorm's num_batches_tracked (int64 device tensor) — incremented by the finalize kernel itself,
-        under the status-word guard, instead of by a separate host-side `+= 1` (None: the caller keeps doing that)."""
+        under the status-word guard, instead of by a separate host-side `+= 1` (None: the caller keeps doing that).
+        ln_width: LayerNorm's width when the layer runs zero-padded to more columns (None: all H columns)."""
         M, H = Wx_raw.shape
         dev = Wx_raw.device
         if mode == "batchnorm":
@@ -530,13 +531,14 @@ class _Norm:
             y = torch.empty_like(Wx_raw)
             mu = torch.empty(M, dtype=torch.float32, device=dev)
             rstd = torch.empty(M, dtype=torch.float32, device=dev)
-            check(lib.sparch_layernorm_fwd(M, H, ptr(Wx_raw), ptr(weight), ptr(bias), NORM_EPS, ptr(y), ptr(mu),
-                                           ptr(rstd), _stream()), "sparch_layernorm_fwd")
+            check(lib.sparch_layernorm_fwd(M, H, ln_width or H, ptr(Wx_raw), ptr(weight), ptr(bias), NORM_EPS, ptr(y),
+                                           ptr(mu), ptr(rstd), _stream()), "sparch_layernorm_fwd")
             return y, None, None, (mu, rstd)
         return Wx_raw, None, None, None
 
     @staticmethod
-    def backward(mode, dy, Wx_raw, weight, saved, training, sums=None, planes=False, dy2=None, keep_fp32=True):
+    def backward(mode, dy, Wx_raw, weight, saved, training, sums=None, planes=False, dy2=None, keep_fp32=True,
+                 ln_width=None):
         """dy (M,H) grad wrt the normalised projection -> (dx_raw, dweight, dbias). May overwrite dy.
         sums = (dbeta, dgamma) when the cell's backward kernel already produced BatchNorm's column sums.
         planes=True (batchnorm, H % 8 == 0): returns (dx_raw or None, dweight, dbias, dx_planes) with dx_planes the
@@ -586,8 +588,8 @@ class _Norm:
             dx = torch.empty_like(dy)
             nbytes = lib.sparch_bn_bwd_workspace_bytes(M, H)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-            check(lib.sparch_layernorm_bwd(M, H, ptr(dy), ptr(Wx_raw), ptr(mu), ptr(rstd), ptr(weight), ptr(dx),
-                                           ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _stream()),
+            check(lib.sparch_layernorm_bwd(M, H, ln_width or H, ptr(dy), ptr(Wx_raw), ptr(mu), ptr(rstd), ptr(weight),
+                                           ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _stream()),
                   "sparch_layernorm_bwd")
             return dx, dgamma, dbeta
         return dy, None, None
@@ -1161,7 +1163,8 @@ class MLPLayerFn(torch.autograd.Function):
         x2 = x.view(M, K)
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))          # anns.py:218
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
-                                                    cfg.get("running_var"), training, 1)          # 221-223
+                                                    cfg.get("running_var"), training, 1,          # 221-223
+                                                    ln_width=cfg.get("ln_width"))
         y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
         check(lib.sparch_act_fwd(ACT_KIND[cfg["act"]], M * H, H, ptr(Wx_in), ptr(scale), ptr(shift),
                                  cfg["p_drop"], cfg["seed"], ptr(y), _stream()), "sparch_act_fwd")  # 226
@@ -1181,7 +1184,8 @@ class MLPLayerFn(torch.autograd.Function):
         dz = torch.empty(M, H, dtype=torch.float32, device=x2.device)
         check(lib.sparch_act_bwd(ACT_KIND[cfg["act"]], M * H, H, ptr(z), ptr(scale), ptr(shift), ptr(_f32c(g_y)),
                                  cfg["p_drop"], cfg["seed"], ptr(dz), _stream()), "sparch_act_bwd")
-        dx_raw, dnw, dnb = _Norm.backward(norm, dz, Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dx_raw, dnw, dnb = _Norm.backward(norm, dz, Wx_raw, nw, ctx.nsaved, cfg["training"],
+                                          ln_width=cfg.get("ln_width"))
         dW = gemm_tn(dx_raw, x2)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
@@ -1249,7 +1253,8 @@ class RNNLayerFn(torch.autograd.Function):
         x2 = x.view(M, K)
         Wx_raw, colstat = gemm_nt(x2, W, Wb, colstat=(norm == "batchnorm" and training))             # anns.py:306
         Wx_in, scale, shift, nsaved = _Norm.forward(norm, Wx_raw, colstat, nw, nb, cfg.get("running_mean"),
-                                                    cfg.get("running_var"), training, dirs)          # 309-311
+                                                    cfg.get("running_var"), training, dirs,          # 309-311
+                                                    ln_width=cfg.get("ln_width"))
         Bp = B * dirs
         y_out = torch.empty(B, T, H * dirs, dtype=torch.float32, device=dev)
         y_state = torch.empty(Bp, T, H, dtype=torch.float32, device=dev)
@@ -1321,7 +1326,8 @@ class RNNLayerFn(torch.autograd.Function):
             check(lib.sparch_add_halves(M * H, ptr(dpre), ptr(dy), _stream()), "sparch_add_halves")
         else:
             dy = dpre
-        dx_raw, dnw, dnb = _Norm.backward(norm, dy.view(M, H), Wx_raw, nw, ctx.nsaved, cfg["training"])
+        dx_raw, dnw, dnb = _Norm.backward(norm, dy.view(M, H), Wx_raw, nw, ctx.nsaved, cfg["training"],
+                                          ln_width=cfg.get("ln_width"))
         dW = gemm_tn(dx_raw, x2)
         dWb = _colsum(dx_raw) if ctx.needs_input_grad[3] else None
         dx = gemm_nn(dx_raw, W).view(B, T, K) if ctx.needs_input_grad[1] else None
@@ -1377,7 +1383,7 @@ class GatedLayerFn(torch.autograd.Function):
         for m in mats:
             raw, colstat = gemm_nt(x2, P[m]["W"], P[m]["Wb"], colstat=(norm == "batchnorm" and training))
             z_in, sc, sh, nsaved = _Norm.forward(norm, raw, colstat, P[m]["nw"], P[m]["nb"], cfg["running"][m][0],
-                                                 cfg["running"][m][1], training, dirs)
+                                                 cfg["running"][m][1], training, dirs, ln_width=cfg.get("ln_width"))
             proj[m] = dict(raw=raw, z_in=z_in, sc=sc, sh=sh, nsaved=nsaved)
         Vgate = torch.cat([P["z"]["V"], P["r"]["V"] if kind == "GRU" else P["c"]["V"]], dim=0).contiguous()  # (2H,H)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -1525,7 +1531,7 @@ class GatedLayerFn(torch.autograd.Function):
             else:
                 dy = d_all[m]
             dx_raw, dnw, dnb = _Norm.backward(norm, dy.view(M, H), Pm[m]["raw"], Pm[m]["nw"], ctx.nsaved[m],
-                                              cfg["training"])
+                                              cfg["training"], ln_width=cfg.get("ln_width"))
             dx_raws.append(dx_raw)
             grads[m] = (gemm_tn(dx_raw, x2), _colsum(dx_raw) if ctx.needs_b[m] else None, dnw, dnb, dV[m])
         dx = None

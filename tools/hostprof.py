@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-side cost of a training step (cfg2 shape by default: adLIF 3x512, B=128 — the host-bound configuration):
 wall time per eagerly launched step with and without cProfile, and the profile's top entries.
-usage: tools/hostprof.py [profile]   (run from the tree to measure: `cd .ab/r2 && python ../../tools/hostprof.py`)"""
+usage: tools/hostprof.py [cfg3] [profile]   (run from the tree to measure: `cd .ab/r2 && python ../../tools/hostprof.py`)"""
 import cProfile
 import io
 import pstats
@@ -15,14 +15,16 @@ import sparch_amd  # noqa: E402
 from sparch_amd import functional as Fn  # noqa: E402
 
 dev = torch.device("cuda", 0)
-B, T, C = 128, 250, 700
+cfg3 = "cfg3" in sys.argv
+B, T, C = (256, 250, 700) if cfg3 else (128, 250, 700)
 torch.manual_seed(1234)
-net = sparch_amd.SNN((B, None, C), [512, 512, 20], neuron_type="adLIF", dropout=0.1, normalization="batchnorm").to(dev).train()
+net = sparch_amd.SNN((B, None, C), [1024, 1024, 35] if cfg3 else [512, 512, 20], neuron_type="RadLIF" if cfg3 else "adLIF",
+                     dropout=0.1, normalization="batchnorm").to(dev).train()
 opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)
 loss_fn = getattr(Fn, "CrossEntropyLoss", torch.nn.CrossEntropyLoss)()
 g = torch.Generator().manual_seed(4321)
 x = (torch.rand(B, T, C, generator=g) < 0.05).float().to(dev)
-y = torch.randint(0, 20, (B,), generator=g).to(dev)
+y = torch.randint(0, 35 if cfg3 else 20, (B,), generator=g).to(dev)
 
 
 def step():
@@ -43,7 +45,7 @@ enq = time.perf_counter() - t0
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
 print(f"eager: host enqueue {1e3 * enq / 200:.3f} ms per step, step {1e3 * tot / 200:.3f} ms")
-if len(sys.argv) > 1:
+if "profile" in sys.argv:
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(100):
