@@ -16,6 +16,7 @@
 // identical inputs the spikes are bit-identical to the eager CPU path.
 // HBM-bound: 12H (LIF) / 16H (adLIF) bytes per sample-step forward, the same backward.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -316,6 +317,291 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellArgs c) {
     }
 }
 
+// ------------------------------------------------------------------ pipelined variants (round 3)
+// The kernels above fetch U steps, wait for ALL of them (`s_waitcnt vmcnt(0)`), compute U steps, and start over:
+// with one wave per SIMD (65 k neurons at BASELINE configs[1] = 1024 waves on 1024 SIMDs) nothing covers the HBM
+// round trip of each batch, and the nullable outputs put a scalar branch around every load and store.  These
+// variants keep a register ring of the next D steps' inputs: every step issues ONE step's loads (D steps ahead,
+// unconditional, clamped into range at the sequence end) and consumes the oldest slot, so the round trip sits behind
+// D steps of arithmetic and stores; which outputs exist is a template parameter (no branch in the loop).  D is
+// bounded by the wave's 6-bit vmcnt (in order, counts stores): with OPS vector-memory operations per step a load
+// older than 63 / OPS steps is forced complete by any counted wait.  Same arithmetic, same order: bit-identical.
+#ifndef CELL_PIPE
+#define CELL_PIPE 1
+#endif
+typedef unsigned cell_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int pipe_depth(int vec, int ops) { return vec == 4 ? 8 : (63 / ops < 16 ? 63 / ops : 16); }
+
+// one saved state (u or w) of VEC neurons as it comes off the wire: fp32, or bf16 words unpacked at the use
+template <int VEC, bool S16> struct SavedVec;
+template <int VEC> struct SavedVec<VEC, false> {
+    float v[VEC];
+    __device__ __forceinline__ void load(const float* base, size_t i) { ldv<VEC>(v, base + i); }
+    __device__ __forceinline__ void expand(float (&d)[VEC]) const {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] = v[e];
+    }
+};
+template <> struct SavedVec<4, true> {
+    unsigned long long raw;
+    __device__ __forceinline__ void load(const float* base, size_t i) {
+        raw = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(base) + i);
+    }
+    __device__ __forceinline__ void expand(float (&d)[4]) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = bf16_to_f32((unsigned short)(raw >> (16 * e)));
+    }
+};
+template <> struct SavedVec<1, true> {
+    unsigned short raw;
+    __device__ __forceinline__ void load(const float* base, size_t i) { raw = reinterpret_cast<const unsigned short*>(base)[i]; }
+    __device__ __forceinline__ void expand(float (&d)[1]) const { d[0] = bf16_to_f32(raw); }
+};
+
+// SAVE: 0 = no saved states (eval), 1 = fp32, 2 = bf16.  SOUT / S16OUT: the fp32 spike tensor / the bf16 plane.
+// DROP: dropout is on (a template parameter: a scalar branch around the mask's hash inside the loop makes hipcc's
+// wait-count pass fall back to `s_waitcnt vmcnt(0)` at the join, once per trip — the ring would drain every D steps)
+template <bool ADAPT, int VEC, int SAVE, bool SOUT, bool S16OUT, bool DROP>
+__global__ __launch_bounds__(256) void cell_fwd_pipe_kernel(CellArgs c) {
+    constexpr int D = pipe_depth(VEC, 1 + (SOUT ? 1 : 0) + (S16OUT ? 1 : 0) + (SAVE ? 1 + (ADAPT ? 1 : 0) : 0));
+    const int HQ = c.H / VEC;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Bp = c.B * c.dirs;
+    if (idx >= (long long)Bp * HQ) return;
+    const int bp = (int)(idx / HQ), h = (int)(idx % HQ) * VEC;
+    const int d = bp / c.B, b = bp - d * c.B;
+    const int T = c.T, H = c.H, HO = c.H * c.dirs;
+
+    float al[VEC], oma[VEC], be[VEC], pa[VEC], pb[VEC], sc[VEC], sh[VEC];
+    float u[VEC], w[VEC], s[VEC];
+    uint32_t cnt[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        al[e] = clampf(c.alpha[h + e], SP_ALPHA_LO, SP_ALPHA_HI);
+        oma[e] = 1.0f - al[e];
+        if (ADAPT) {
+            be[e] = clampf(c.beta[h + e], SP_BETA_LO, SP_BETA_HI);
+            pa[e] = clampf(c.a[h + e], SP_A_LO, SP_A_HI);
+            pb[e] = clampf(c.b[h + e], SP_B_LO, SP_B_HI);
+        }
+        sc[e] = c.scale ? c.scale[h + e] : 1.0f;
+        sh[e] = c.scale ? c.shift[h + e] : 0.0f;
+        cnt[e] = 0;
+    }
+    ldv<VEC>(u, c.u0 + (size_t)bp * H + h);
+    ldv<VEC>(s, c.s0 + (size_t)bp * H + h);
+    if (ADAPT) ldv<VEC>(w, c.w0 + (size_t)bp * H + h);
+    const bool has_norm = c.scale != nullptr;
+    constexpr bool drop = DROP;
+    const uint64_t seed = drop ? resolve_seed(c.seed) : 0;
+
+    const float* xrow = c.Wx + (size_t)b * T * H + h;
+    auto fetch = [&](float (&x)[VEC], int t) __attribute__((always_inline)) {
+        const int tc = min(t, T - 1);  // past the end: a step that is in range and never used
+        ldv<VEC>(x, xrow + (size_t)(d ? (T - 1 - tc) : tc) * H);
+    };
+    auto step = [&](int t, const float (&x)[VEC]) __attribute__((always_inline)) {
+        const int tt = d ? (T - 1 - t) : t;
+        float so[VEC];
+        const size_t o = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float xn = x[e];
+            if (has_norm) xn = bn_affine(xn, sc[e], sh[e]);
+            float drive = xn;
+            if (ADAPT) {
+                w[e] = (be[e] * w[e] + pa[e] * u[e]) + pb[e] * s[e];  // snns.py:438
+                drive = xn - w[e];
+            }
+            u[e] = al[e] * (u[e] - s[e]) + oma[e] * drive;           // snns.py:297 / 439
+            s[e] = (u[e] - c.theta) > 0.0f ? 1.0f : 0.0f;            // snns.py:29
+            const float k = drop ? keep_scale(seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+            so[e] = s[e] * k;
+            cnt[e] += (so[e] != 0.0f) ? 1u : 0u;
+        }
+        if (SOUT) stv<VEC>(c.s_out + o, so);
+        if (S16OUT) {
+            if constexpr (VEC == 4) {
+                cell_u32x2 pk;
+                pk.x = (so[0] != 0.0f ? 0x3F80u : 0u) | (so[1] != 0.0f ? 0x3F800000u : 0u);
+                pk.y = (so[2] != 0.0f ? 0x3F80u : 0u) | (so[3] != 0.0f ? 0x3F800000u : 0u);
+                *reinterpret_cast<cell_u32x2*>(c.s16_out + o) = pk;
+            } else {
+                c.s16_out[o] = so[0] != 0.0f ? (uint16_t)0x3F80 : (uint16_t)0;
+            }
+        }
+        if (SAVE) {
+            st_saved<VEC, true>(c.u_save, ((size_t)bp * T + t) * H + h, u, SAVE == 2, c.theta);
+            if (ADAPT) st_saved<VEC, false>(c.w_save, ((size_t)bp * T + t) * H + h, w, SAVE == 2, c.theta);
+        }
+    };
+
+    float ring[D][VEC];
+#pragma unroll
+    for (int j = 0; j < D; ++j) fetch(ring[j], j);
+    // every prologue load is in before the loop is entered: hipcc's counted waits inside the loop are the merge of
+    // this state and the back edge's — with the D fills still in flight here, slot 0 looks "14 operations old" on
+    // every trip (`vmcnt(14)`, then 17, 19 ...) instead of a full ring old (`vmcnt(56)`)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int t0 = 0;
+    for (; t0 + D <= T; t0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            // consume, THEN refill the slot: issued ahead of the step's arithmetic the new value is live beside the
+            // old one, the two cannot share a register, and hipcc's copies at the loop's back edge wait for every
+            // load of the ring (`s_waitcnt vmcnt(4)` per trip: the pipeline drained every D steps)
+            step(t0 + j, ring[j]);
+            fetch(ring[j], t0 + j + D);
+            // (the trip is one basic block: without this hipcc gathers the D refills at one end of it, and the first
+            // slots are waited for a few operations after their issue)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (t0 + j >= T) break;
+        step(t0 + j, ring[j]);
+    }
+    if (c.spike_count) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (cnt[e]) atomicAdd(c.spike_count + (size_t)d * H + h + e, cnt[e]);
+    }
+}
+
+template <bool ADAPT, int VEC, bool S16, bool BN, bool DROP>
+__global__ __launch_bounds__(256) void cell_bwd_pipe_kernel(CellArgs c) {
+    constexpr int D = pipe_depth(VEC, 3 + (ADAPT ? 1 : 0) + (BN ? 1 : 0));
+    const int HQ = c.H / VEC;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Bp = c.B * c.dirs;
+    if (idx >= (long long)Bp * HQ) return;
+    const int bp = (int)(idx / HQ), h = (int)(idx % HQ) * VEC;
+    const int d = bp / c.B, b = bp - d * c.B;
+    const int T = c.T, H = c.H, HO = c.H * c.dirs;
+
+    float al[VEC], oma[VEC], be[VEC], pa[VEC], pb[VEC], gr[VEC];
+    float du_n[VEC], dw_n[VEC], u_t[VEC];
+    float acc_al[VEC], acc_be[VEC], acc_a[VEC], acc_b[VEC];
+    float bn_mu[VEC], bn_is[VEC], acc_dy[VEC], acc_dyx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        bn_mu[e] = BN ? c.bn_mean[h + e] : 0.f;
+        bn_is[e] = BN ? c.bn_invstd[h + e] : 0.f;
+        acc_dy[e] = acc_dyx[e] = 0.f;
+        al[e] = clampf(c.alpha[h + e], SP_ALPHA_LO, SP_ALPHA_HI);
+        oma[e] = 1.0f - al[e];
+        if (ADAPT) {
+            be[e] = clampf(c.beta[h + e], SP_BETA_LO, SP_BETA_HI);
+            pa[e] = clampf(c.a[h + e], SP_A_LO, SP_A_HI);
+            pb[e] = clampf(c.b[h + e], SP_B_LO, SP_B_HI);
+        }
+        gr[e] = c.g_rate ? c.g_rate[(size_t)d * H + h + e] * c.g_rate_scale : 0.0f;
+        du_n[e] = dw_n[e] = 0.f;
+        acc_al[e] = acc_be[e] = acc_a[e] = acc_b[e] = 0.f;
+    }
+    ld_saved<VEC>(u_t, c.u_save, ((size_t)bp * T + (T - 1)) * H + h, S16);
+    // the initial states: read by cell step 0 (the last of the reverse pass) only; fetched here, off the loop
+    float u0v[VEC], w0v[VEC], s0v[VEC];
+    ldv<VEC>(u0v, c.u0 + (size_t)bp * H + h);
+    ldv<VEC>(s0v, c.s0 + (size_t)bp * H + h);
+    if (ADAPT) ldv<VEC>(w0v, c.w0 + (size_t)bp * H + h);
+    constexpr bool drop = DROP;
+    const uint64_t seed = drop ? resolve_seed(c.seed) : 0;
+
+    struct Slot { float g[VEC]; float xr[BN ? VEC : 1]; SavedVec<VEC, S16> up; SavedVec<VEC, S16> wp; };
+    const float* grow = c.g_out + (size_t)b * T * HO + (size_t)d * H + h;
+    const float* xrow = BN ? c.bn_x + (size_t)b * T * H + h : nullptr;
+    const size_t srow = (size_t)bp * T * H + h;
+    auto fetch = [&](Slot& q, int t) __attribute__((always_inline)) {
+        const int tc = max(t, 0);  // before the start: a step that is in range and never used
+        const int tt = d ? (T - 1 - tc) : tc;
+        ldv<VEC>(q.g, grow + (size_t)tt * HO);
+        if constexpr (BN) ldv<VEC>(q.xr, xrow + (size_t)tt * H);
+        const size_t i = srow + (size_t)max(tc - 1, 0) * H;  // cell step 0 reads row 0 (unused: u0 / w0 below)
+        q.up.load(c.u_save, i);
+        if (ADAPT) q.wp.load(c.w_save, i);
+    };
+    // FIRST: the step may be cell step 0 (tail of the reverse pass only — the main loop stops before it)
+    auto step = [&](int t, const Slot& q, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int tt = d ? (T - 1 - t) : t;
+        const size_t o = ((size_t)b * T + tt) * HO + (size_t)d * H + h;
+        float up[VEC], wp[VEC], sp[VEC], dwx[VEC];
+        q.up.expand(up);
+        if (ADAPT) q.wp.expand(wp);
+        const bool t0 = FIRST && t == 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (t0) { up[e] = u0v[e]; if (ADAPT) wp[e] = w0v[e]; }
+            sp[e] = t0 ? s0v[e] : ((up[e] - c.theta) > 0.0f ? 1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float k = drop ? keep_scale(seed, o + e, c.p_drop, c.inv_keep) : 1.0f;
+            const float gs = (q.g[e] + gr[e]) * k;
+            float ds = gs - al[e] * du_n[e];
+            if (ADAPT) ds = ds + pb[e] * dw_n[e];
+            const float xs = u_t[e] - c.theta;
+            float du = boxcar_gate(ds, xs) + al[e] * du_n[e];            // snns.py:33-35
+            if (ADAPT) du = du + pa[e] * dw_n[e];
+            dwx[e] = oma[e] * du;
+            if (BN) {  // BatchNorm backward's column sums (dy = dWx, xhat = (x - mean) * invstd)
+                acc_dy[e] += dwx[e];
+                acc_dyx[e] += dwx[e] * ((q.xr[BN ? e : 0] - bn_mu[e]) * bn_is[e]);
+            }
+            const float qq = up[e] - sp[e];
+            acc_al[e] += du * (qq - u_t[e]);  // d u_t / d alpha = (q - u_t)/(1-alpha); scaled at the end
+            if (ADAPT) {
+                const float dw = be[e] * dw_n[e] - dwx[e];
+                acc_be[e] += dw * wp[e];
+                acc_a[e] += dw * up[e];
+                acc_b[e] += dw * sp[e];
+                dw_n[e] = dw;
+            }
+            du_n[e] = du;
+            // carried into the next step as a COPY made here: kept in the slot's own register the value outlives the
+            // slot's refill, the refill needs another register, and hipcc shuffles the whole ring through `v_mov`s in
+            // mid-loop — each of which waits for a load issued a few operations earlier
+            asm volatile("v_mov_b32 %0, %1" : "=&v"(u_t[e]) : "v"(up[e]));
+        }
+        stv<VEC>(c.dWx + ((size_t)bp * T + tt) * H + h, dwx);
+    };
+
+    Slot ring[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) fetch(ring[j], T - 1 - j);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // see the forward kernel
+    int i0 = 0;  // reverse index: step t = T - 1 - i
+    for (; i0 + D <= T - 1; i0 += D) {  // steps t >= 1 only
+#pragma unroll
+        for (int j = 0; j < D; ++j) {  // consume, then refill (see the forward kernel)
+            step(T - 1 - (i0 + j), ring[j], std::false_type{});
+            fetch(ring[j], T - 1 - (i0 + j + D));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (i0 + j >= T) break;
+        step(T - 1 - (i0 + j), ring[j], std::true_type{});
+    }
+    const size_t plane = (size_t)Bp * H;
+    float* ws = c.dparam_ws + (size_t)bp * H + h;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc_al[e] = acc_al[e] / oma[e];
+    stv<VEC>(ws, acc_al);
+    if (ADAPT) {
+        stv<VEC>(ws + plane, acc_be);
+        stv<VEC>(ws + 2 * plane, acc_a);
+        stv<VEC>(ws + 3 * plane, acc_b);
+    }
+    if (BN) {
+        stv<VEC>(ws + 4 * plane, acc_dy);
+        stv<VEC>(ws + 5 * plane, acc_dyx);
+    }
+}
+
 // ------------------------------------------------------------------ readout cell
 // Readout layer (snns.py:815-825): u_t = alpha u_{t-1} + (1-alpha) x_t, out = sum_t softmax_c(u_t).
 // One workgroup of 256 threads per batch row; a chunk of up to 256 time steps (the whole sequence for the
@@ -603,6 +889,32 @@ __global__ __launch_bounds__(RO_NT) void readout_bwd_kernel(int B, int T, int C,
     }
 }
 
+template <bool ADAPT, int VEC, bool DROP>
+void launch_cell_pipe(bool bwd, const CellArgs& c, unsigned blocks, hipStream_t st) {
+    if (bwd) {
+        auto go = [&](auto s16, auto bn) {
+            hipLaunchKernelGGL((cell_bwd_pipe_kernel<ADAPT, VEC, decltype(s16)::value, decltype(bn)::value, DROP>),
+                               dim3(blocks), dim3(256), 0, st, c);
+        };
+        if (c.save16) { if (c.bn_x) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
+        else          { if (c.bn_x) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }
+        return;
+    }
+    auto go = [&](auto save, auto sout, auto s16out) {
+        hipLaunchKernelGGL((cell_fwd_pipe_kernel<ADAPT, VEC, decltype(save)::value, decltype(sout)::value,
+                                                 decltype(s16out)::value, DROP>),
+                           dim3(blocks), dim3(256), 0, st, c);
+    };
+    auto outs = [&](auto save) {
+        if (c.s_out && c.s16_out) go(save, std::true_type{}, std::true_type{});
+        else if (c.s_out) go(save, std::true_type{}, std::false_type{});
+        else go(save, std::false_type{}, std::true_type{});
+    };
+    if (!c.u_save) outs(std::integral_constant<int, 0>{});
+    else if (c.save16) outs(std::integral_constant<int, 2>{});
+    else outs(std::integral_constant<int, 1>{});
+}
+
 template <bool ADAPT>
 int launch_cell(bool bwd, CellArgs& c, hipStream_t st) {
     const long long work = (long long)c.B * c.dirs * c.H;
@@ -611,6 +923,11 @@ int launch_cell(bool bwd, CellArgs& c, hipStream_t st) {
     const bool vec4 = vec_ok && work >= (long long)256 * 8 * 64 * 4;
     const long long threads = vec4 ? work / 4 : work;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
+#if CELL_PIPE
+    const bool drop = c.p_drop > 0.0f;
+    if (vec4) { if (drop) launch_cell_pipe<ADAPT, 4, true>(bwd, c, blocks, st); else launch_cell_pipe<ADAPT, 4, false>(bwd, c, blocks, st); }
+    else      { if (drop) launch_cell_pipe<ADAPT, 1, true>(bwd, c, blocks, st); else launch_cell_pipe<ADAPT, 1, false>(bwd, c, blocks, st); }
+#else
 #define SP_CELL_LAUNCH(KERNEL, S16)                                                                     \
     do {                                                                                                \
         if (vec4) hipLaunchKernelGGL((KERNEL<ADAPT, 4, S16>), dim3(blocks), dim3(256), 0, st, c);       \
@@ -622,6 +939,7 @@ int launch_cell(bool bwd, CellArgs& c, hipStream_t st) {
         if (c.save16) SP_CELL_LAUNCH(cell_bwd_kernel, true); else SP_CELL_LAUNCH(cell_bwd_kernel, false);
     }
 #undef SP_CELL_LAUNCH
+#endif
     SPARCH_CHECK_LAUNCH();
     return SPARCH_OK;
 }
@@ -646,6 +964,7 @@ extern "C" int sparch_cell_fwd(int kind, int B, int dirs, int T, int H, const fl
     if (B <= 0 || T <= 0 || H <= 0 || (dirs != 1 && dirs != 2) || !Wx || !alpha || !u0 || !s0 || (!s_out && !s16_out))
         return SPARCH_EINVAL;
     if (adapt && (!beta || !a || !b || !w0)) return SPARCH_EINVAL;
+    if (adapt && ((u_save == nullptr) != (w_save == nullptr))) return SPARCH_EINVAL;  // saved together or not at all
     if ((scale == nullptr) != (shift == nullptr)) return SPARCH_EINVAL;
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return SPARCH_EINVAL;
     if (!ptrs_aligned({Wx, u0, w0, s0, s_out, u_save, w_save})) return SPARCH_EALIGN;

@@ -100,8 +100,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // the device address of a uint64 holding the seed (SPARCH_SEED_IN_MEMORY; the host advances that word between
 // replays).  Resolved once per thread at kernel entry.
 __device__ __forceinline__ uint64_t resolve_seed(uint64_t seed_or_address) {
-    if (seed_or_address & SPARCH_SEED_IN_MEMORY)
-        return *reinterpret_cast<const uint64_t*>(seed_or_address & ~SPARCH_SEED_IN_MEMORY);
+    // (read through the constant address space — the word only changes between launches: a generic pointer here is
+    // a FLAT load, which hipcc cannot count; its wait, `vmcnt(0) lgkmcnt(0)`, lands at the seed's first use INSIDE the
+    // callers' time loops and drains their prefetch pipelines once per trip)
+    typedef const uint64_t __attribute__((address_space(4))) * seed_ptr;
+    if (seed_or_address & SPARCH_SEED_IN_MEMORY) return *(seed_ptr)(seed_or_address & ~SPARCH_SEED_IN_MEMORY);
     return seed_or_address;
 }
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {

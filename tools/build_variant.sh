@@ -8,7 +8,8 @@ cd "$(dirname "$0")/../sparch_amd/csrc"
 make -s -j8 all
 mkdir -p ../../.ab/$NAME
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I../../include -Wall -Wno-unused-function "$@" -c $SRC -o ../../.ab/$NAME/${SRC%.hip}.o
+EXTRA=""; [ "$SRC" = cell.hip ] && EXTRA="-fno-slp-vectorize"   # as the Makefile's FLAGS_cell
+$HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I../../include -Wall -Wno-unused-function $EXTRA "$@" -c $SRC -o ../../.ab/$NAME/${SRC%.hip}.o
 OBJS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
 $HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS ../../.ab/$NAME/${SRC%.hip}.o -o ../libsparch_hip_$NAME.so
 echo built sparch_amd/libsparch_hip_$NAME.so
