@@ -545,6 +545,12 @@ int sparch_adam_step(int n_tensors, float* const* params, const float* const* gr
                      float weight_decay, const float* scalars_dev, uint32_t* skip_if_nonzero,
                      void* stream);
 
+/* The per-step factors of a captured step, made on the device by ONE launch: t_dev (double, the step count) += 1;
+ * scalars_dev[0] = lr_dev[0] / (1 - beta1^t), scalars_dev[1] = sqrt(1 - beta2^t), evaluated in double precision as the
+ * host path does (replaces a dozen captured scalar torch ops per step, ~55 us of a 1 ms BASELINE configs[1] step). */
+int sparch_adam_scalars(double* t_dev, const double* lr_dev, double beta1, double beta2, float* scalars_dev,
+                        void* stream);
+
 /* ---- G1/G2, round 3: the gradient of a BatchNorm'd projection as bf16 planes, made ONCE.
  * sparch_bn_bwd_apply_planes = sparch_bn_bwd_apply (dx = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M)) writing dx as
  * its three exact bf16 planes (3 x M x H uint16, truncation split: dx = t1 + t2 + t3 — the split the dense GEMMs

@@ -126,6 +126,7 @@ PROTOTYPES = {
                                           P, c_size_t, P, c_int]),
     "sparch_expand_counts_u8": (c_int, [ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P]),
     "sparch_ce_loss": (c_int, [c_int, c_int, P, P, P, P, P]),
+    "sparch_adam_scalars": (c_int, [P, P, c_double, c_double, P, P]),
     "sparch_adam_step": (c_int, [c_int, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
 }
 

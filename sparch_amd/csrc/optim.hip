@@ -66,7 +66,28 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch a) {
     }
 }
 
+// one thread: t += 1, then the two per-step factors in double precision (the host path's formula)
+__global__ void adam_scalars_kernel(double* t, const double* lr, double beta1, double beta2, float* scalars) {
+    const double tt = *t + 1.0;
+    *t = tt;
+    const double bc1 = 1.0 - pow(beta1, tt);
+    const double bc2 = 1.0 - pow(beta2, tt);
+    scalars[0] = (float)(*lr / bc1);
+    scalars[1] = (float)sqrt(bc2);
+}
+
 }  // namespace
+
+extern "C" int sparch_adam_scalars(double* t_dev, const double* lr_dev, double beta1, double beta2,
+                                   float* scalars_dev, void* stream) {
+    SPARCH_ENTER();
+    if (!t_dev || !lr_dev || !scalars_dev || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        return SPARCH_EINVAL;
+    hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_dev, lr_dev, beta1, beta2,
+                       scalars_dev);
+    SPARCH_CHECK_LAUNCH();
+    return SPARCH_OK;
+}
 
 extern "C" int sparch_adam_step(int n_tensors, float* const* params, const float* const* grads,
                                 float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,

@@ -37,9 +37,12 @@ class GraphedTrainStep:
         self.x, self.y = x.clone(), y.clone()
         dev = x.device
         # device-resident per-step values
-        for lay in net.snn:
-            lay._seed_word = torch.zeros(1, dtype=torch.int64, device=dev)
-            lay._seed_word.fill_(int(torch.cuda.initial_seed() & 0x3FFFFFFFFFFFFFFF) + 7919 * getattr(lay, "_layer_index", 0))
+        base = int(torch.cuda.initial_seed() & 0x3FFFFFFFFFFFFFFF)
+        self._seeds = torch.tensor([base + 7919 * getattr(lay, "_layer_index", 0) for lay in net.snn],
+                                   dtype=torch.int64).to(dev)  # one word per layer, advanced together (one node)
+        for i, lay in enumerate(net.snn):
+            lay._seed_word = self._seeds[i:i + 1]
+            lay._seed_word_owner_advances = True
         optimizer.enable_graph_mode()
         feats = self.front_end(self.x) if self.front_end is not None else self.x
         self._batch = feats.shape[0]
@@ -65,6 +68,7 @@ class GraphedTrainStep:
             self._body()
 
     def _body(self):
+        self._seeds.add_(1)
         self.opt.zero_grad(set_to_none=True)
         feats = self.front_end(self.x) if self.front_end is not None else self.x
         out, rates = self.net(feats)
@@ -94,5 +98,6 @@ class GraphedTrainStep:
     def close(self):
         for lay in self.net.snn:
             lay._seed_word = None
+            lay._seed_word_owner_advances = False
         self.net._static_states = None
         self.opt._g = None

@@ -133,10 +133,8 @@ class Adam(torch.optim.Optimizer):
         group, g = self.param_groups[0], self._g
         ps = [p for p in group["params"] if p.grad is not None]
         beta1, beta2 = group["betas"]
-        g["t"].add_(1.0)
-        bc1 = 1.0 - torch.pow(torch.full_like(g["t"], beta1), g["t"])
-        bc2 = 1.0 - torch.pow(torch.full_like(g["t"], beta2), g["t"])
-        g["scalars"].copy_(torch.stack([g["lr"] / bc1, torch.sqrt(bc2)]).to(torch.float32))
+        check(lib.sparch_adam_scalars(g["t"].data_ptr(), g["lr"].data_ptr(), float(beta1), float(beta2),
+                                      g["scalars"].data_ptr(), _stream()), "sparch_adam_scalars")
         if not torch.cuda.is_current_stream_capturing():
             self.note_replay()
         self._launch(ps, 0.0, beta1, beta2, 1.0, group["eps"], group["weight_decay"], scalars=g["scalars"])

@@ -312,6 +312,7 @@ class _SpikingLayer(nn.Module):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_seed_word", None)  # graph mode's device-side dropout seed: a step's state, not the network's
+        state.pop("_seed_word_owner_advances", None)
         return state
 
     # ------------------------------------------------------------------ helpers
@@ -338,7 +339,8 @@ class _SpikingLayer(nn.Module):
         if word is not None:
             # graph mode (sparch_amd.graph): the seed lives in device memory and is advanced by a captured op,
             # the kernels get its address (a kernel argument would be frozen at capture time)
-            word.add_(1)
+            if not getattr(self, "_seed_word_owner_advances", False):  # (the captured step advances all layers' words at once)
+                word.add_(1)
             return Fn.SEED_IN_MEMORY | word.data_ptr()
         self._calls = getattr(self, "_calls", 0) + 1
         index = getattr(self, "_layer_index", 0)
