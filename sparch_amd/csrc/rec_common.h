@@ -57,6 +57,11 @@ constexpr int TILE_BYTES = RT * CT * 4;  // one fp32 hand-off tile
 #ifndef REC_BWD_PROBE
 #define REC_BWD_PROBE 0  /* backward: probe one dword per producer sample before issuing a step's tile loads (measured with one k-group ahead: 1.117 vs 1.040 ms per launch — the probe is one more round trip; with two or more ahead the kernel spills) */
 #endif
+#ifndef REC_BWD_UPPER_DELAY
+#define REC_BWD_UPPER_DELAY 0   // s_sleep units (64 cycles) before the upper waves' first tile loads of a backward step.
+                                // Measured (40 launches x 3, one call): 0 -> 1.029 ms per launch, 4 -> 1.040, 8 -> 1.049,
+                                // 14 -> 1.074: the upper waves are the LATE ones at the reduction barrier, not early pollers
+#endif
 #ifndef REC_AHEAD
 #define REC_AHEAD 1  /* k-groups whose tile loads are issued ahead of the one being multiplied */
 #endif

@@ -799,6 +799,12 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 }
             }
 #endif
+#if REC_BWD_UPPER_DELAY
+            // (experiment: the waves without pointwise state reach this point a few hundred cycles before the others;
+            // if their first k-group is requested before the peers' tiles have landed it costs them a second round
+            // trip, and the pointwise waves then wait for them at the reduction barrier)
+            if (NW == 8 && CW == 1 && !pw_wave) __builtin_amdgcn_s_sleep(REC_BWD_UPPER_DELAY);
+#endif
 #pragma unroll
             for (int kk = 0; kk < AHEAD; ++kk) issue_ptile<NW, NP>(raw[kk], rsrc, base, wave + NW * kk, a.n_ct);
             PROF_STAMP(0);  // first tile load issue
