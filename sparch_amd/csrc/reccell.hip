@@ -106,9 +106,15 @@ __device__ u64 g_rec_prof[2][512][12];
         if ((i) >= 0) pf_acc[(i) < 0 ? 0 : (i)] += now_ - pf_t;                                 \
         pf_t = now_;                                                                            \
     } while (0)
+#ifdef SPARCH_REC_PROF_ALLWAVES  /* every wave of the first 64 workgroups: slot = workgroup * 8 + wave */
+#define PROF_FLUSH(which)                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64)                                             \
+        for (int i_ = 0; i_ < 10; ++i_) g_rec_prof[which][blockIdx.x * 8 + (threadIdx.x >> 6)][i_] += pf_acc[i_];
+#else
 #define PROF_FLUSH(which)                                                                       \
     if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 256)  /* wave 0, and wave 4 in slots 256.. */ \
         for (int i_ = 0; i_ < 10; ++i_) g_rec_prof[which][blockIdx.x + (threadIdx.x ? 256 : 0)][i_] += pf_acc[i_];
+#endif
 #else
 #define PROF_DECL
 #define PROF_STAMP(i)

@@ -47,6 +47,14 @@ print(f"fwd+bwd wall {e0.elapsed_time(e1):.3f} ms, firing rate {float(s.mean()):
 names = [["poll wait", "mfma+lds", "barrier", "pointwise+publish", "bulk stores", "-", "-", "-", "-", "-"],
          ["first load issue", "wait+split+mfma+lds", "barrier", "split+publish stores", "publish barrier", "stores+partial sums",
           "settle+prefetch issue", "tile reduction", "reverse-step arithmetic", "-"]]
+if "allwaves" in sys.argv:  # library built with -DSPARCH_REC_PROF_ALLWAVES: one line per wave (mean over 64 workgroups)
+    for w, label in [(0, "forward"), (1, "backward")]:
+        a = buf[w, :, :10].astype(np.float64).reshape(64, 8, 10) / T
+        print(f"{label}: cycles per step and wave (mean over 64 workgroups); columns: " + " | ".join(n for n in names[w] if n != "-"))
+        for wave in range(8):
+            print(f"   wave {wave}: " + " ".join(f"{a[:, wave, i].mean():7.0f}" for i in range(10) if names[w][i] != "-")
+                  + f"   sum {a[:, wave].sum(1).mean():7.0f}")
+    sys.exit(0)
 for w, label in [(0, "forward"), (1, "backward"), (2, "forward, wave 4"), (3, "backward, wave 4")]:
     a = buf[w % 2, 256 * (w // 2):256 * (w // 2) + 256, :10].astype(np.float64) / T
     w = w % 2
