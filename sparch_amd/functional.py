@@ -610,7 +610,7 @@ def spike_placeholder(B, T, F, device):
 
 
 def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_drop, seed, steps_per_launch=None,
-                 want_s_out=True):
+                 want_s_out=True, want_saves=True):
     """Run one spiking cell over the whole sequence on the device.
 
     Wx (B,T,H) raw projection (+ optional per-column scale/shift); u0/w0/s0 (B*dirs,H).
@@ -618,7 +618,9 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
     s_out != 0 as a bf16 plane (or None).  want_s_out=False (round 3): the fp32 tensor is not written — s_out is
     None — when the bf16 plane exists, i.e. for a layer whose output only feeds the next layer's spike GEMMs
     (the reference materialises it because its next op is a dense nn.Linear, snns.py:261; here it was 4 of the
-    14 bytes a recurrent forward step stores per element)."""
+    14 bytes a recurrent forward step stores per element).  want_saves=False (LIF / adLIF, nothing will be
+    differentiated — validation and test forwards, exp.py:405-518): u / w are not saved either (8 of an adLIF step's
+    14 bytes); `saved` is then (None, None)."""
     _, T, H = Wx.shape
     Bp = B * dirs
     dev = Wx.device
@@ -633,8 +635,9 @@ def cell_forward(kind, Wx, scale, shift, p, u0, w0, s0, *, B, dirs, theta, p_dro
     # from the saved state, which must then be exact)
     save16 = SAVE_BF16 and H % 4 == 0 and (not recurrent or (L >= T and not rec_step_path(H)))
     sdt = torch.bfloat16 if save16 else torch.float32
-    u_save = torch.empty(Bp, T, H, dtype=sdt, device=dev)
-    w_save = torch.empty(Bp, T, H, dtype=sdt, device=dev) if adaptive else None
+    want_saves = want_saves or recurrent  # (the recurrent kernels always save)
+    u_save = torch.empty(Bp, T, H, dtype=sdt, device=dev) if want_saves else None
+    w_save = torch.empty(Bp, T, H, dtype=sdt, device=dev) if (adaptive and want_saves) else None
     count = torch.zeros(H * dirs, dtype=torch.int32, device=dev)
     if not recurrent:
         tok = timer.start(f"cell_fwd[{kind}]")
@@ -845,7 +848,8 @@ class SpikingLayerFn(torch.autograd.Function):
             cfg["states_ready"]()
         s_out, count, saved, s16 = cell_forward(kind, Wx_in.view(B, T, H), scale, shift, p, u0, w0, s0, B=B,
                                                 dirs=dirs, theta=theta, p_drop=p_drop, seed=seed,
-                                                want_s_out=cfg.get("fp32_out", True))
+                                                want_s_out=cfg.get("fp32_out", True),
+                                                want_saves=any(ctx.needs_input_grad))
         if s_out is None:
             s_out = spike_placeholder(B, T, H * dirs, x.device)
         inv_keep = 1.0 / (1.0 - p_drop)
@@ -1017,7 +1021,7 @@ class SpikingCellFn(torch.autograd.Function):
         Bp, T, H = Wx.shape
         p = {k_: v for k_, v in dict(alpha=alpha, beta=beta, a=a, b=b, V=V).items() if v is not None}
         s, _, saved, _ = cell_forward(kind, Wx, None, None, p, u0, w0, s0, B=Bp, dirs=1, theta=theta, p_drop=0.0,
-                                      seed=0, steps_per_launch=steps_per_launch)
+                                      seed=0, steps_per_launch=steps_per_launch, want_saves=any(ctx.needs_input_grad))
         ctx.kind, ctx.theta, ctx.dims, ctx.cell_saved, ctx.spl = kind, theta, (Bp, T, H), saved, steps_per_launch
         ctx.save_for_backward(alpha, beta, a, b, V, u0, w0, s0)
         return s

@@ -816,6 +816,53 @@ def test_cell_kernels_shape_fuzz_vs_oracle():
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("save16", [False, True])
+def test_scan_kernels_around_the_prefetch_ring_depths(save16, monkeypatch):
+    """LIF / adLIF scan kernels (round 3: a register ring of the next D steps' inputs, D = 8 ... 16 by variant —
+    csrc/cell.hip): sequence lengths on both sides of every ring depth and of its multiples (the loop's main trips,
+    the tail without refills, cell step 0 inside the tail), one neuron per thread and — 512 x 1024 neurons — four per
+    thread; fp32 and bf16 saved states.  Spikes bit-equal to the oracle, dWx to 2e-4 of max-abs in both modes, the
+    neuron-parameter gradients to 2e-4 (fp32 saves) / 5e-2 (bf16 saves); evaluation forwards (no saved states:
+    another kernel variant) give the same spikes."""
+    Fn = _Fn()
+    monkeypatch.setattr(Fn, "SAVE_BF16", save16)
+    bad = []
+    cases = [(3, T, 5) for T in (6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49)]
+    cases += [(512, T, 1024) for T in (7, 8, 9, 17)]  # 524288 neurons: the four-neurons-per-thread variant (D = 8)
+    for kind in ("adLIF", "LIF"):
+        adapt = kind == "adLIF"
+        for Bp, T, H in cases:
+            Wx, p, u0, w0, s0, gs = _dyadic_cell_case("RadLIF" if adapt else "RLIF", Bp, T, H, 11 * T + Bp)
+            p.pop("V")
+            p = {k: v.requires_grad_(True) for k, v in p.items()}
+            Wx.requires_grad_(True)
+            ref = orc.spiking_cell(kind, Wx, p, u0, w0 if adapt else None, s0)
+            (ref * gs).sum().backward()
+            pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in p.items()}
+            Wxd = Wx.detach().to(DEV).requires_grad_(True)
+            s = Fn.SpikingCellFn.apply(kind, 1.0, Wxd, pd["alpha"], pd.get("beta"), pd.get("a"), pd.get("b"), None,
+                                       u0.to(DEV), w0.to(DEV) if adapt else None, s0.to(DEV), None)
+            (s * gs.to(DEV)).sum().backward()
+            e = relmax(Wxd.grad.cpu().numpy(), Wx.grad.numpy())
+            eg = max(relmax(pd[k].grad.cpu().numpy(), p[k].grad.numpy()) for k in p)
+            # bf16 saves: dWx depends on the saved states only through the discrete decisions (same bar); the neuron
+            # parameters' sums see u / w rounded to 2^-9 — 5e-2 of max-abs here, where 7-9 steps leave little to average
+            tol_p = 5e-2 if save16 else 2e-4
+            if not torch.equal(s.detach().cpu(), ref.detach()) or not e <= 2e-4 or not eg <= tol_p:
+                bad.append((kind, Bp, T, H, e, eg))
+            # evaluation mode: no saved states (another kernel variant), same spikes
+            with torch.no_grad():
+                s_eval = Fn.SpikingCellFn.apply(kind, 1.0, Wxd.detach(), pd["alpha"].detach(),
+                                                None if not adapt else pd["beta"].detach(),
+                                                None if not adapt else pd["a"].detach(),
+                                                None if not adapt else pd["b"].detach(), None, u0.to(DEV),
+                                                w0.to(DEV) if adapt else None, s0.to(DEV), None)
+            if not torch.equal(s_eval.cpu(), ref.detach()):
+                bad.append((kind, Bp, T, H, "eval"))
+    Fn.check_status()
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
 def test_snn_random_configurations_vs_oracle(sp, compute, request):
     """(fp32: the bars below; bf16 operand mode: spike counts still equal — the dyadic weights are bf16-exact — and
