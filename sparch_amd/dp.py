@@ -78,12 +78,12 @@ def choose_policy(layers):
     return "window" if has_persistent_layers(layers) else "overlap"
 
 
-def sync_status(device, group=None):
+def sync_status(device, group=None, force=False):
     """Make the recurrent kernels' status word the same on every rank (MAX of the raised flag, on the device, no
     host synchronisation).  Call before anything that branches on it — `functional.check_status` at an epoch
     end, the bench's checks — so that all ranks degrade or raise together instead of one leaving its peers in a
     collective."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     from . import functional as Fn
 
@@ -112,6 +112,11 @@ class GradAllReducer:
         self.overlap = policy != "deferred"  # some collective runs under the backward pass
         self.rows_per_rank = rows_per_rank
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # collectives are issued when there is a peer — or when SPARCH_DP_FORCE_COLLECTIVES=1 asks for them in a
+        # one-rank group (tools/nccl_world1_check.py: the only way to run the RCCL calls, their stream semantics and
+        # their coexistence with the persistent kernels on a one-GPU box; a sum over one rank is the identity)
+        self._collective = self.world > 1 or (dist.is_initialized()
+                                              and os.environ.get("SPARCH_DP_FORCE_COLLECTIVES", "0") == "1")
         if buckets is None:
             layers = getattr(module, "snn", None) or getattr(module, "ann", None)  # SNN / ANN layer lists
             if layers is not None:
@@ -166,7 +171,7 @@ class GradAllReducer:
 
     def _bucket_complete(self, bi):
         self._log("ready", bi)
-        if self.world == 1 or self.policy == "deferred":
+        if not self._collective or self.policy == "deferred":
             return
         self._flatten(bi)
         if self.policy == "overlap":
@@ -188,7 +193,7 @@ class GradAllReducer:
         """Right behind a persistent launch: the buckets that became ready before it go out now; their
         collective starts when that kernel has finished (stream order) and runs under the GEMMs that follow."""
         self._log("post", len(self._ready))
-        if self.world == 1:
+        if not self._collective:
             return
         for bi in self._ready:
             self._launch(bi)
@@ -202,7 +207,7 @@ class GradAllReducer:
         for bi, bucket in enumerate(self.buckets):
             if self._pending[bi] not in (0, len(bucket)):
                 raise RuntimeError("GradAllReducer: a bucket received only part of its gradients")
-        if self.world > 1 and self.policy == "deferred":
+        if self._collective and self.policy == "deferred":
             ps = [p for bi, bucket in enumerate(self.buckets) if self._pending[bi] == 0 for p in bucket]
             if ps:
                 flat = torch.cat([p.grad.reshape(-1) for p in ps])
@@ -214,7 +219,7 @@ class GradAllReducer:
                     n = p.numel()
                     p.grad = flat[off:off + n].view_as(p)
                     off += n
-        elif self.world > 1:
+        elif self._collective:
             for bi in self._ready:  # window: what no persistent launch followed (the input layer's bucket)
                 self._launch(bi)
             self._ready, self._inflight = [], []
@@ -231,8 +236,8 @@ class GradAllReducer:
                     n = p.numel()
                     p.grad = flat[off:off + n].view_as(p)
                     off += n
-        if self.world > 1 and self.status_device is not None:
-            sync_status(self.status_device, self.group)
+        if self._collective and self.status_device is not None:
+            sync_status(self.status_device, self.group, force=self.world == 1)
         self.reset()
 
     def remove(self):

@@ -44,3 +44,27 @@ def test_two_ranks_on_one_gpu_gradients_and_syncbn():
         assert "data-parallel checks passed" in out
         assert "forced overlap on a full grid finished" in out
         assert "a timeout on one rank skips the step on both" in out
+
+
+@pytest.mark.gpu
+def test_rccl_backend_with_one_rank():
+    """The `nccl` (= RCCL) backend itself, which the gloo rehearsals never touch: a one-rank process group with the
+    collectives forced on (tools/nccl_world1_check.py) — init, async all-reduces on RCCL's stream under every launch
+    policy with gradients bit-identical to the reducer-less step, the window policy's launch order, the status word's
+    MAX all-reduce, a captured step with the all-reduce inside.  In its own process: it owns the process group."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    with __import__("socket").socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sock.getsockname()[1])
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_check.py")], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "nccl_world1_check.log"), "w") as f:
+        f.write(p.stdout)
+    # (the tool prints this line behind its last check and leaves through os._exit: the verdict is the line, not
+    # whatever RCCL's or HIP's exit handlers do afterwards)
+    assert "nccl world-size-1 checks passed" in p.stdout, p.stdout[-4000:]
+    for policy in ("overlap", "window", "deferred"):
+        assert f"policy {policy}" in p.stdout
