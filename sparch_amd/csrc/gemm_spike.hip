@@ -117,14 +117,30 @@ template <bool KM, int ROWS>
 __device__ __forceinline__ bool tile_is_full(int row0, int rows, int k0, int kend, int vec) {
     return vec && row0 + ROWS <= rows && k0 + BK <= kend;
 }
-template <bool KM, int ROWS, int NT>
+// GEMM_NT (bit mask, experiment, OFF): non-temporal hints for what a product touches once — 1: the row-major
+// activation operand of the pipelined kernels, 2: the C tiles of products with a row-major A (the big activations /
+// gradients), 4: both K-major streams of the TN products.  Measured on the cfg3 step in one call (round 3): 0 -> 6.49
+// ms, 1 -> 6.62-6.77, 3 -> 6.56-6.60, 7 -> 6.54-6.65: the products themselves do not change and the kernel BEHIND a
+// hinted product slows down (rec_bwd after dX: 2.09 -> 2.14-2.24 ms) — its input no longer waits in the infinity cache.
+#ifndef GEMM_NT
+#define GEMM_NT 0
+#endif
+// (a weight matrix is never streamed: it is the operand every tile of the product re-reads)
+template <bool A_KM, bool B_KM> constexpr bool stream_a() { return (!A_KM && (GEMM_NT & 1)) || (A_KM && B_KM && (GEMM_NT & 4)); }
+template <bool A_KM, bool B_KM> constexpr bool stream_b() { return A_KM && B_KM && (GEMM_NT & 4); }
+template <bool STREAM>
+__device__ __forceinline__ f32x4 ld16(const void* q) {
+    if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+    else return *reinterpret_cast<const f32x4*>(q);
+}
+template <bool KM, int ROWS, int NT, bool STREAM = false>
 __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const float* __restrict__ P, int ld,
                                            int row0, int rows, int k0, int kend, int vec, int tid) {
     constexpr int RQ = ROWS / 4;  // pieces per k row of a KM tile
     const int f = tid + NT * p;
     if (fast) {
-        if constexpr (!KM) out = *reinterpret_cast<const f32x4*>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
-        else               out = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + f / RQ) * ld + row0 + ((f % RQ) << 2));
+        if constexpr (!KM) out = ld16<STREAM>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
+        else               out = ld16<STREAM>(P + (size_t)(k0 + f / RQ) * ld + row0 + ((f % RQ) << 2));
         return;
     }
     int row, k;
@@ -159,7 +175,7 @@ __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const f
 // ---- the same for a spike operand held as a bf16 plane (0 / 1.0; SURVEY f: the producers write it next to
 // their fp32 output): 8 elements per 16-byte piece, half the bytes through the CU's L1 fill path — which,
 // beside the matrix pipe, is what bounds these kernels.
-template <bool KM, int ROWS, int NT>
+template <bool KM, int ROWS, int NT, bool STREAM = false>
 __device__ __forceinline__ void load_piece16(f32x4& out, int p, bool fast, const unsigned short* __restrict__ P,
                                              int ld, int row0, int rows, int k0, int kend, int vec, int tid) {
     constexpr int RQ = ROWS / 8;  // pieces per k row of a KM tile
@@ -168,7 +184,7 @@ __device__ __forceinline__ void load_piece16(f32x4& out, int p, bool fast, const
     if constexpr (!KM) { row = row0 + (f >> 2); k = k0 + ((f & 3) << 3); }
     else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 3); }
     const unsigned short* q = KM ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
-    if (fast) { out = *reinterpret_cast<const f32x4*>(q); return; }
+    if (fast) { out = ld16<STREAM>(q); return; }
     u32x4 v = {0u, 0u, 0u, 0u};
     const bool outer_ok = KM ? (k < kend) : (row < rows);
     const int inner = KM ? row : k, inner_end = KM ? rows : kend;
@@ -446,20 +462,21 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         }
     };
     // global -> registers, full in-range tile at K offset k (FAST only)
+    constexpr bool STR_A = stream_a<A_KM, B_KM>(), STR_B = stream_b<A_KM, B_KM>();
     auto fetch_piece = [&](auto& ra, auto& rb, int q, int k) __attribute__((always_inline)) {
         if (q < NPA) {
             if constexpr (APRE)
-                load_piece16<A_KM, BM, NT>(ra[q], q % NPA1, true, g.Ap + (q / NPA1) * g.ap_stride, g.lda, m0, g.M, k, k_end, 1, tid);
+                load_piece16<A_KM, BM, NT, STR_A>(ra[q], q % NPA1, true, g.Ap + (q / NPA1) * g.ap_stride, g.lda, m0, g.M, k, k_end, 1, tid);
             else if constexpr (A16)
-                load_piece16<A_KM, BM, NT>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
-            else load_piece<A_KM, BM, NT>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
+                load_piece16<A_KM, BM, NT, STR_A>(ra[q], q, true, reinterpret_cast<const unsigned short*>(g.A), g.lda, m0, g.M, k, k_end, 1, tid);
+            else load_piece<A_KM, BM, NT, STR_A>(ra[q], q, true, g.A, g.lda, m0, g.M, k, k_end, 1, tid);
         } else if (q < NPA + NPB) {
             if constexpr (BPRE)
-                load_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, true, g.Bp + ((q - NPA) / NPB1) * g.bp_stride, g.ldb, n0,
+                load_piece16<B_KM, BN, NT, STR_B>(rb[q - NPA], (q - NPA) % NPB1, true, g.Bp + ((q - NPA) / NPB1) * g.bp_stride, g.ldb, n0,
                                            g.N, k, k_end, 1, tid);
             else if constexpr (B16)
-                load_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, reinterpret_cast<const unsigned short*>(g.B), g.ldb, n0, g.N, k, k_end, 1, tid);
-            else load_piece<B_KM, BN, NT>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
+                load_piece16<B_KM, BN, NT, STR_B>(rb[q - NPA], q - NPA, true, reinterpret_cast<const unsigned short*>(g.B), g.ldb, n0, g.N, k, k_end, 1, tid);
+            else load_piece<B_KM, BN, NT, STR_B>(rb[q - NPA], q - NPA, true, g.B, g.ldb, n0, g.N, k, k_end, 1, tid);
         }
     };
 
@@ -678,7 +695,8 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
                 // back to back (a predicated store is its own basic block, and hipcc then waits for the
                 // previous store's acknowledgement, vmcnt(0), in each one)
                 if (FAST || (row < g.M && col < g.N)) {
-                    Cz[(size_t)row * g.ldc + col] = v;
+                    if constexpr (FAST && !A_KM && (GEMM_NT & 2)) __builtin_nontemporal_store(v, Cz + (size_t)row * g.ldc + col);
+                    else Cz[(size_t)row * g.ldc + col] = v;
                     if constexpr (EPI & EPI_STATS) { csum[j] += v; csq[j] += v * v; }
                 }
             }

@@ -73,14 +73,41 @@ constexpr unsigned SENTINEL = 0x7FA5A5A5u;
 
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Non-temporal hints for what a time loop touches ONCE (round 3).  The loops stream their inputs (projection rows,
+// incoming gradient, saved states) and outputs (saved states, spike planes, dWx) through the same L2 that holds what
+// they re-read every step — the hand-off granules / ring tiles, the V pack — and at 2-4 MB per step per XCD the
+// streams push those lines out: the backward ring (6 MB, rewritten every 4 steps) was written back to HBM on every
+// pass (WRITE_SIZE 734 -> 490 MiB per launch with the hints: the ring now stays in L2), and the forward's polls and
+// LUT / V reads missed.  Measured in one call, per launch in isolation: forward 0.636 -> 0.615 (loads) -> 0.597 ms
+// (loads + stores), backward 1.024 -> 1.004 -> 1.003; in the cfg3 step (two layers): forward 1.195 -> 1.15 (loads),
+// 1.09 (stores), 1.04 ms (both), step 6.58 -> 6.38 ms.  (The same hints on the split GEMMs' activation operands and
+// C tiles LOSE: 6.49 -> 6.55-6.77 ms — a GEMM's output is the next kernel's input and should stay in the 256 MB
+// infinity cache; `rec_bwd` right behind the dX product slowed down by 3-7 %.)
+#ifndef REC_NT_LOADS
+#define REC_NT_LOADS 1
+#endif
+__device__ __forceinline__ f32x4 ld4s(const float* p) {  // a streaming input: read once
+#if REC_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
 #ifndef REC_NT_STORES
-#define REC_NT_STORES 0  /* bulk output stores of the recurrent kernels as non-temporal stores (measured: no change) */
+#define REC_NT_STORES 1  /* bulk output stores of the recurrent kernels as non-temporal stores (see REC_NT_LOADS) */
 #endif
 __device__ __forceinline__ void st4(float* p, f32x4 v) {
 #if REC_NT_STORES
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
     *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st2(void* p, u32x2 v) {  // an 8-byte bulk output (bf16 plane quads, bf16 saves)
+#if REC_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#else
+    *reinterpret_cast<u32x2*>(p) = v;
 #endif
 }
 // saved states (u, w) as fp32 or bf16 (element index i)
@@ -99,7 +126,7 @@ template <> struct SavedRaw<true> { typedef u32x2 type; };
 template <bool S16>
 __device__ __forceinline__ typename SavedRaw<S16>::type ld_saved_raw(const float* base, size_t i) {
     if constexpr (S16) return *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + i);
-    else return ld4(base + i);
+    else return ld4s(base + i);
 }
 __device__ __forceinline__ f32x4 expand_saved(const f32x4& r) { return r; }
 __device__ __forceinline__ f32x4 expand_saved(const u32x2& r) {
@@ -115,7 +142,7 @@ __device__ __forceinline__ void st4_saved(float* base, size_t i, f32x4 v, bool s
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         raw |= (unsigned long long)(IS_U ? save_u16(v[e], theta) : f32_to_bf16_rne(v[e])) << (16 * e);
-    *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(base) + i) = raw;
+    st2(reinterpret_cast<unsigned short*>(base) + i, u32x2{(unsigned)raw, (unsigned)(raw >> 32)});
 }
 
 // Workgroup barrier for LDS hand-offs inside the time loops.  __syncthreads() also carries workgroup-scope

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
         return a.Wx + ((size_t)b * T + tt) * H + colc;
     };
     f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
-    if (pw) x_next = ld4(wx_ptr(a.t_begin));
+    if (pw) x_next = ld4s(wx_ptr(a.t_begin));
     // The recurrent drive of the launch's FIRST step (t = 0: s0 @ V from the host; step variants: the caller's
     // product) and the projection row of its second step are loaded HERE, not inside the loop: a global load on
     // one path of the loop body only (round 2 had `if (t == 0) rec = ld4(rec0)`) makes hipcc's wait-count pass
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
     f32x4 rec_first = {0.f, 0.f, 0.f, 0.f}, x_second = rec_first;
     if (first_ext) {
         rec_first = ld4(a.rec0 + (size_t)bpc * H + colc);
-        if (pw && a.t_begin + 1 < a.t_end) x_second = ld4(wx_ptr(a.t_begin + 1));
+        if (pw && a.t_begin + 1 < a.t_end) x_second = ld4s(wx_ptr(a.t_begin + 1));
     }
     // Bulk HBM stores of a step are held back (12 VGPRs) and issued only after the NEXT step's poll loads:
     // vmcnt retires in order and counts stores, so stores (and the Wx prefetch) issued ahead of the poll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             u32x2 h;
             h.x = (vs[0] != 0.f ? 0x3F80u : 0u) | (vs[1] != 0.f ? 0x3F800000u : 0u);
             h.y = (vs[2] != 0.f ? 0x3F80u : 0u) | (vs[3] != 0.f ? 0x3F800000u : 0u);
-            *reinterpret_cast<u32x2*>(a.s16_out + o_s) = h;
+            st2(a.s16_out + o_s, h);
         }
         st4_saved<true>(a.u_save, ((size_t)bp * T + st_t) * H + col, vu, a.save16, a.theta);
         if (ADAPT) st4_saved<false>(a.w_save, ((size_t)bp * T + st_t) * H + col, vw, a.save16, a.theta);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
             // register allocator placed it at the loop latch, with a `vmcnt(0)` in front of the next poll)
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = x_next[e];
-            if (pw && t + 1 < a.t_end) x_next = ld4(wx_ptr(t + 1));
+            if (pw && t + 1 < a.t_end) x_next = ld4s(wx_ptr(t + 1));
             flush_pending();
             // ---- s_{t-1} @ V on the bf16 MFMA: spikes expanded through the LDS table (lane
             //      (row li, k-half hh) takes byte 2*ks + hh of its row's 32-bit word)
@@ -688,8 +688,8 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
     auto load_step = [&](int t, f32x4& g, saved_raw& up, saved_raw& wp, f32x4& xr) {
         const int tt = d ? (T - 1 - t) : t;
         const float* gp = a.g_out + ((size_t)b * T + tt) * HO + (size_t)d * H + colc;
-        g = ld4(gp);
-        xr = ld4(a.bn_src + ((size_t)b * T + tt) * H + colc);
+        g = ld4s(gp);
+        xr = ld4s(a.bn_src + ((size_t)b * T + tt) * H + colc);
         const size_t o = ((size_t)bpc * T + (size_t)max(t - 1, 0)) * H + colc;
         up = ld_saved_raw<S16>(a.u_save, o);
         if (ADAPT) wp = ld_saved_raw<S16>(a.w_save, o);
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         if (BXS && valid_hi && t + 1 < a.t_end) {  // the previous step's staged outputs -> HBM (upper waves)
             const int t1 = t + 1, tt1 = d ? (T - 1 - t1) : t1;
             st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
-            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt1) * H + col) = stage_sp[tid & 255];
+            st2(a.s_prev16 + ((size_t)bp * T + tt1) * H + col, stage_sp[tid & 255]);
         }
         // From here to the publish barrier: the waves that own pointwise state only (a WAVE-UNIFORM branch, round 3
         // — until then the upper four waves ran the reduction reads and the whole reverse step on dead values and
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                 stage_dwx[tid] = dwx; stage_sp[tid] = h;
             } else {
                 st4(a.dWx + ((size_t)bp * T + tt) * H + col, dwx);
-                *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt) * H + col) = h;
+                st2(a.s_prev16 + ((size_t)bp * T + tt) * H + col, h);
             }
         }
         if (pw) {
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
         if (!aborted && valid_hi && a.t_end > a.t_begin) {
             const int t1 = a.t_begin, tt1 = d ? (T - 1 - t1) : t1;
             st4(a.dWx + ((size_t)bp * T + tt1) * H + col, stage_dwx[tid & 255]);
-            *reinterpret_cast<u32x2*>(a.s_prev16 + ((size_t)bp * T + tt1) * H + col) = stage_sp[tid & 255];
+            st2(a.s_prev16 + ((size_t)bp * T + tt1) * H + col, stage_sp[tid & 255]);
         }
 #endif
     }
