@@ -15,7 +15,7 @@ for V in sys.argv[1:]:
         try:
             d = json.loads(open(f"gpurun_out/abl_{V}_{rep}.json").read().strip().splitlines()[-1])
             k = d.get("kernels_ms_per_step", {})
-            big = {n.split("[")[0] + "[" + n.split("[")[1][:18]: round(v, 3) for n, v in k.items() if v > 0.1}
+            big = {n.split("[")[0] + "[" + n.split("[")[1][:18]: round(v, 3) for n, v in k.items() if v > 0.05}
             print(f"{V:6s} {d['ms_per_step']:.3f} ms  {big}")
         except Exception as e:
             print(V, rep, "failed", e)
