@@ -127,7 +127,11 @@ __device__ __forceinline__ bool tile_is_full(int row0, int rows, int k0, int ken
 #endif
 // (a weight matrix is never streamed: it is the operand every tile of the product re-reads)
 template <bool A_KM, bool B_KM> constexpr bool stream_a() { return (!A_KM && (GEMM_NT & 1)) || (A_KM && B_KM && (GEMM_NT & 4)); }
-template <bool A_KM, bool B_KM> constexpr bool stream_b() { return A_KM && B_KM && (GEMM_NT & 4); }
+// 8: the spike plane of the TN products whose spikes are the layer's INPUT (dW = dx^T * s_in, MODE 1): written by the
+//    forward pass long ago and read here for the last time, beside a dx that the dX product behind reads again
+template <bool A_KM, bool B_KM, int MODE = 0> constexpr bool stream_b() {
+    return A_KM && B_KM && ((GEMM_NT & 4) || (MODE == 1 && (GEMM_NT & 8)));
+}
 template <bool STREAM>
 __device__ __forceinline__ f32x4 ld16(const void* q) {
     if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
@@ -462,7 +466,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         }
     };
     // global -> registers, full in-range tile at K offset k (FAST only)
-    constexpr bool STR_A = stream_a<A_KM, B_KM>(), STR_B = stream_b<A_KM, B_KM>();
+    constexpr bool STR_A = stream_a<A_KM, B_KM>(), STR_B = stream_b<A_KM, B_KM, MODE>();
     auto fetch_piece = [&](auto& ra, auto& rb, int q, int k) __attribute__((always_inline)) {
         if (q < NPA) {
             if constexpr (APRE)
