@@ -305,16 +305,29 @@ def main():
             for _ in range(args.warmup):
                 step()
     graphed = None
+    run_step = step
     if graph_mode == "on":
         from sparch_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, loss_fn, x, y, reducer=reducer,
-                                   front_end=(lambda a: Fn.fbank(a, num_mel_bins=C)) if audio else None,
-                                   warmup=max(1, args.warmup))
-        run_step = graphed.step
-        for _ in range(max(1, args.warmup)):  # untimed replays: the first launch of an instantiated graph uploads it
-            graphed.step()                    # (several ms; it sat inside the 20-step timed region: cfg2 1.55 vs 1.14 ms)
-    else:
-        run_step = step
+        try:
+            graphed = GraphedTrainStep(net, opt, loss_fn, x, y, reducer=reducer,
+                                       front_end=(lambda a: Fn.fbank(a, num_mel_bins=C)) if audio else None,
+                                       warmup=max(1, args.warmup))
+            for _ in range(max(1, args.warmup)):  # untimed replays: the first launch of an instantiated graph uploads it
+                graphed.step()                    # (several ms; it sat inside the 20-step timed region: cfg2 1.55 vs 1.14 ms)
+            torch.cuda.synchronize()
+            if os.environ.get("SPARCH_BENCH_FAIL_CAPTURE") == "1":  # exercises the fallback below
+                raise RuntimeError("capture failure requested by SPARCH_BENCH_FAIL_CAPTURE")
+            run_step = graphed.step
+        except Exception as e:  # a failed capture must not cost the measurement: say so and launch eagerly
+            if args.graph == "on":
+                raise
+            print(f"[bench] rank {rank}: capturing the step failed ({type(e).__name__}: {str(e)[:300]}); launching eagerly",
+                  file=sys.stderr, flush=True)
+            graph_why += f"; capture failed ({type(e).__name__}), eager instead"
+            GraphedTrainStep.abandon(net, opt)
+            graphed = None
+            for _ in range(max(1, args.warmup)):
+                step()
     if not kernels_ok("warm-up"):
         for _ in range(max(1, args.warmup)):  # degraded to per-step launches: warm those up
             step()

@@ -95,6 +95,15 @@ class GraphedTrainStep:
         self.opt.note_replay()
         return self.loss
 
+    @staticmethod
+    def abandon(net, optimizer):
+        """Undo what a (possibly failed) construction left on the network and the optimizer: back to eager steps."""
+        for lay in net.snn:
+            lay._seed_word = None
+            lay._seed_word_owner_advances = False
+        net._static_states = None
+        optimizer._g = None
+
     def close(self):
         for lay in self.net.snn:
             lay._seed_word = None
