@@ -357,7 +357,11 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_fwd_kernel(RecArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
+#ifdef REC_FWD_ABL2  // timing ablation (wrong results): two of the three planes
+                    for (int p = NP - 1; p >= (NP == 3 ? 1 : 0); --p)
+#else
                     for (int p = NP - 1; p >= 0; --p)
+#endif
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
 #if defined(SPARCH_REC_PROF) && defined(FA_NO_MFMA)  // timing ablation (wrong results): operands kept alive, no MFMA
@@ -844,9 +848,13 @@ __global__ __launch_bounds__(64 * NW, 1) void rec_bwd_kernel(RecArgs a) {
                     // |x||V|), t2*lo (<= 2^-23) and t3*lo.  Worst-case per product; summed over a row the
                     // dropped part measures 3e-9 of sum|x||V| (7 terms: 1.4e-9; an fp32 sgemm's own
                     // rounding: 1e-7) — the same kind of cut as the dense 6-term GEMM.
+#ifndef REC_BWD_ABL3  // (timing ablation, wrong results: the three largest terms only)
                     acc[0] = mfma_bf16(p2, vb[0][kk][ks][NP == 3], acc[0]);  // t2*mid
                     acc[0] = mfma_bf16(p3, vb[0][kk][ks][0], acc[0]);  // t3*hi
                     acc[0] = mfma_bf16(p1, vl, acc[0]);       // t1*lo
+#else
+                    asm volatile("" ::"v"(p3), "v"(vl));
+#endif
                     acc[0] = mfma_bf16(p2, vb[0][kk][ks][0], acc[0]);  // t2*hi
                     acc[0] = mfma_bf16(p1, vb[0][kk][ks][NP == 3], acc[0]);  // t1*mid
                     acc[0] = mfma_bf16(p1, vb[0][kk][ks][0], acc[0]);  // t1*hi
