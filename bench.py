@@ -88,20 +88,20 @@ def bf16_issue_factor(name):
     return None  # gemm_auto_*: decided on the device (3 for bf16-exact inputs, else 6)
 
 
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950
-    FETCH_SIZE correction applied).  bench.py cannot run the profiler on itself; None if absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            break
-    else:
+def pmc_traffic(kernel_label, workload="cfg3", low=False):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/r03_pmc_traffic_<workload>[_bf16].json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE
+    correction applied; tools/collect_round3.sh + tools/summarize_round3.sh).  bench.py cannot run the profiler on
+    itself; None where no pass of the workload is tracked."""
+    name = f"r03_pmc_traffic_{workload}{'_bf16' if low else ''}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
         return None, None
     with open(path) as f:
         table = json.load(f)
-    src = {"file": "profiles/" + os.path.basename(path), "commit": table.get("_meta", {}).get("commit")}
-    want = {"rec_cell_bwd": "rec_bwd_kernel", "rec_cell_fwd": "rec_fwd_kernel"}
+    src = {"file": "profiles/" + name, "commit": table.get("_meta", {}).get("commit")}
+    want = {"rec_cell_bwd": "rec_bwd_kernel", "rec_cell_fwd": "rec_fwd_kernel", "cell_bwd": "cell_bwd_pipe_kernel",
+            "cell_fwd": "cell_fwd_pipe_kernel"}
     for prefix, kname in want.items():
         if kernel_label.startswith(prefix):
             for k, v in table.items():
@@ -391,7 +391,7 @@ def main():
             if bound == "mfma":
                 ach = amount / avg_s / 1e12
                 peak = PEAK_MFMA_BF16_TFLOPS if low else PEAK_MFMA_F32_TFLOPS  # bf16 mode: one bf16 MFMA per product
-                traffic, traffic_src = (None, None) if low else pmc_traffic(dom)
+                traffic, traffic_src = pmc_traffic(dom, args.workload, low)
                 roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                         "avg_ms": kern[dom]["avg_ms"]}
@@ -403,8 +403,11 @@ def main():
                     roof["bf16_products_per_fp32_product"] = k6
             else:
                 ach = amount / avg_s / 1e9
+                traffic, traffic_src = pmc_traffic(dom, args.workload, low)
                 roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": kern[dom]["avg_ms"]}
+                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "avg_ms": kern[dom]["avg_ms"]}
+                if traffic_src is not None:
+                    roof["traffic_profile"] = traffic_src
         print(f"[bench] gpu: {value:.0f} ts*samples/s, {ms:.2f} ms/step; dominant {dom}; "
               f"timing the CPU oracle sample next", file=sys.stderr, flush=True)
         cpu = None

@@ -14,7 +14,6 @@ stats cfg4      "round 3: rocprofv3 --kernel-trace --stats of bench.py --workloa
 stats cfg5_bf16 "round 3: rocprofv3 --kernel-trace --stats of bench.py --workload cfg5 --compute-dtype bf16 --steps 5 --warmup 2" 7
 stats cfg5      "round 3: rocprofv3 --kernel-trace --stats of bench.py --workload cfg5 --steps 3 --warmup 1 (fp32)" 4
 for c in cfg3 cfg3_bf16 cfg2 cfg4 cfg5_bf16; do pmc $c "$c"; mfma $c "$c"; done
-cp $P/r03_pmc_traffic_cfg3.json $P/r03_pmc_traffic.json   # what bench.py's roofline.traffic reads
 cp $G/r3_bench_lines.jsonl $P/r03_bench_lines.jsonl
 cp $G/r3_rec_anatomy.txt $P/r03_rec_cycle_anatomy.txt
 ls $P | grep -c r03
