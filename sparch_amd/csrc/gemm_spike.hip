@@ -458,6 +458,9 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             else if constexpr (NP == 1 && !SPIKE_A) store_piece_rne1<A_KM, BM, NT>(ra[q], q, st, tid);
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
         } else if (q < NPA + NPB) {
+#ifdef GEMM_ABL_B
+            if (MODE == 2) { asm volatile("" ::"v"(rb[q - NPA])); return; }
+#endif
             if constexpr (BPRE)  // plane (q - NPA) / NPB1 straight into its LDS image: no conversion
                 store_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, st + A_PLANES * PLANE_A + ((q - NPA) / NPB1) * PLANE_B, tid);
             else if constexpr (B16) store_piece16<B_KM, BN, NT>(rb[q - NPA], q - NPA, st + A_PLANES * PLANE_A, tid);
@@ -510,6 +513,11 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
+#ifdef GEMM_ABL_B  // timing ablation (wrong results): the dense x dense kernels without the B operand's LDS traffic —
+                   // dX [64000 x 1024 x 1024] 0.712 -> 0.542 ms (round 3): the bound on what W fragments loaded straight
+                   // from a fragment-ordered pack in L2 (no LDS staging of the weight planes) could give that product
+        if (MODE == 2) { asm volatile("" : "+v"(fb[ks][0][0]), "+v"(fb[ks][0][1]), "+v"(fb[ks][0][NP - 1])); return; }
+#endif
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
 #pragma unroll
