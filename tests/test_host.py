@@ -193,3 +193,27 @@ def test_snn_draw_states_order_and_fallback(monkeypatch):
     for x, y, z in zip(flat(a), flat(b), ref):
         assert torch.equal(x, y) and torch.equal(x, z)
     assert torch.equal(ta, tb)
+
+
+def test_bench_roofline_traffic_comes_from_the_profile_of_the_workload_run():
+    """bench.py's `roofline.traffic` is read from the tracked PMC passes (bench.py cannot profile itself): the file
+    must be the one of the workload and precision actually run — a cfg4 / cfg5 line carried the headline workload's
+    bytes before round 3 fixed the lookup — and carry the commit it was collected on; no file, no number."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    by_wl = {}
+    for wl, low in (("cfg3", False), ("cfg3", True), ("cfg4", False), ("cfg5", True)):
+        val, src = bench.pmc_traffic("rec_cell_bwd[RadLIF]", wl, low)
+        assert val is not None and val > 1e8, (wl, low)
+        assert src["file"] == f"profiles/r03_pmc_traffic_{wl}{'_bf16' if low else ''}.json" and src["commit"]
+        by_wl[(wl, low)] = val
+    assert len(set(by_wl.values())) == len(by_wl)            # four workloads, four different byte counts
+    assert by_wl[("cfg3", False)] < 1.6 * 16 * 1024 * 64000  # the backward kernel within 1.6x its algorithmic bytes
+    val, src = bench.pmc_traffic("cell_bwd[adLIF]", "cfg2", False)
+    assert val is not None and src["file"].endswith("cfg2.json")
+    assert bench.pmc_traffic("rec_cell_bwd[RadLIF]", "cfg5", False) == (None, None)  # no fp32 pass of cfg5 is tracked
+    assert bench.pmc_traffic("gemm_nn[64000x1024x1024]", "mlp", False) == (None, None)
