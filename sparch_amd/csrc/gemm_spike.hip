@@ -459,7 +459,7 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
             else store_piece<A_KM, BM, NT, SPIKE_A, true>(ra[q], q, st, tid, g.e_exact);
         } else if (q < NPA + NPB) {
 #ifdef GEMM_ABL_B
-            if (MODE == 2) { asm volatile("" ::"v"(rb[q - NPA])); return; }
+            if (MODE == 2 || MODE == 0) { asm volatile("" ::"v"(rb[q - NPA])); return; }
 #endif
             if constexpr (BPRE)  // plane (q - NPA) / NPB1 straight into its LDS image: no conversion
                 store_piece16<B_KM, BN, NT>(rb[q - NPA], (q - NPA) % NPB1, st + A_PLANES * PLANE_A + ((q - NPA) / NPB1) * PLANE_B, tid);
@@ -513,9 +513,11 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 fa[ks][i][p] = frag_read<A_KM, BM>(As + p * PLANE_A, (wm * WI + i) * 32, lane, ks);
-#ifdef GEMM_ABL_B  // timing ablation (wrong results): the dense x dense kernels without the B operand's LDS traffic —
-                   // dX [64000 x 1024 x 1024] 0.712 -> 0.542 ms (round 3): the bound on what W fragments loaded straight
-                   // from a fragment-ordered pack in L2 (no LDS staging of the weight planes) could give that product
+#ifdef GEMM_ABL_B  // timing ablation (wrong results): the weight operand's LDS traffic (staging stores + fragment reads)
+                   // dropped.  Standalone on random operands (tools/gemm_sweep.py, round 3): NT with statistics 383 ->
+                   // 330 us, dX 746 -> 635 us — the bound on what W fragments loaded straight from a fragment-ordered pack
+                   // in L2 could give (-14 %; inside the training step the ablated run reads 0.71 -> 0.54 ms, but there
+                   // its garbage output turns the next steps' operands into NaNs, which draw less power: clocks, not LDS)
         if (MODE == 2) { asm volatile("" : "+v"(fb[ks][0][0]), "+v"(fb[ks][0][1]), "+v"(fb[ks][0][NP - 1])); return; }
 #endif
 #pragma unroll
@@ -535,6 +537,9 @@ __global__ __launch_bounds__((Shape<MODE, FAST>::NT), (Shape<MODE, FAST>::OCC)) 
         }
     };
     auto read_dense = [&](const unsigned short* st, int buf, int ks, int p) __attribute__((always_inline)) {
+#ifdef GEMM_ABL_B  // (the same ablation for the spike x weight products)
+        if (SPIKE_A) { asm volatile("" : "+v"(fd[buf][0])); return; }
+#endif
 #pragma unroll
         for (int j = 0; j < WD; ++j) {
             if constexpr (SPIKE_A)
