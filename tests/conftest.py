@@ -24,6 +24,28 @@ def pytest_sessionstart(session):
                        stdout=subprocess.DEVNULL)
 
 
+def _cgroup_cpus():
+    """CPUs the container may actually use (cgroup quota), or None: a GPU box can show 256 CPUs in the affinity mask
+    under a 16-CPU quota, and the CPU oracle on 256 threads inside that quota crawls (bench.py usable_cpus)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        return None
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads_within_the_cpu_quota():
+    quota = _cgroup_cpus()
+    if quota is not None:
+        import torch
+
+        if torch.get_num_threads() > quota:
+            torch.set_num_threads(quota)
+    yield
+
+
 def _has_gpu():
     """device_count() does not initialise the GPU in this process (is_available() would): the first test of a
     GPU session starts child processes that must come before any GPU use of the parent."""
