@@ -244,6 +244,9 @@ def main():
     if share:
         torch.cuda.set_device(0)
     rank, world, local = dp.init_from_env(backend)
+    # a process group exists: N > 1, or a one-rank group forced on to run this file's distributed branch on RCCL
+    # with one GPU (SPARCH_DP_FORCE_COLLECTIVES=1 under torch.distributed.run --nproc-per-node 1)
+    multi = dist.is_initialized()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if share:
@@ -270,8 +273,8 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}  # for the CPU baseline leg
     opt = sparch_amd.optim.Adam(net.parameters(), 1e-2)  # exp.py:89 (same arithmetic, one launch: SURVEY f-2)
     loss_fn = Fn.CrossEntropyLoss()                 # exp.py:100 (one launch for the loss and its gradient)
-    reducer = dp.GradAllReducer(net, rows_per_rank=B) if world > 1 else None
-    if world > 1 and args.sync_bn:
+    reducer = dp.GradAllReducer(net, rows_per_rank=B) if multi else None
+    if multi and args.sync_bn:
         Fn.SYNC_BN = {"group": None, "world": world}
     g = torch.Generator().manual_seed(4321 + rank)
     audio = w.get("audio")
@@ -303,8 +306,8 @@ def main():
         kernel and the time step).  N > 1: every rank reports what it saw, all ranks switch to one launch per time
         step together and the caller repeats the region — a rank that raised alone used to leave its peers
         waiting in the next collective (round 2's "a rank exited")."""
-        if world > 1:
-            dp.sync_status(dev)
+        if multi:
+            dp.sync_status(dev, force=world == 1)
         if not Fn.poll_status(dev):
             return True
         info = Fn.describe_timeout()
@@ -329,7 +332,7 @@ def main():
         enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         tot = time.perf_counter() - t0
-        graph_mode = "on" if (spiking and world == 1 and enq >= 0.8 * tot) else "off"
+        graph_mode = "on" if (spiking and not multi and enq >= 0.8 * tot) else "off"
         graph_why = f"auto: host enqueue {1e3 * enq / 3:.2f} ms of a {1e3 * tot / 3:.2f} ms step during warm-up"
     else:
         graph_why = "as requested"
@@ -368,7 +371,7 @@ def main():
     def timed_region():
         Fn.timer.reset()
         Fn.timer.enabled = graphed is None  # HIP events per named call exist only for eagerly launched kernels
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -376,7 +379,7 @@ def main():
             loss_ = run_step()
         host_dt_ = time.perf_counter() - t0  # host time to ENQUEUE the steps (close to dt = the host is the bound)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         dt_ = time.perf_counter() - t0
         Fn.timer.enabled = False
@@ -401,7 +404,7 @@ def main():
         kernels_ok("instrumented eager steps")
         roof_note = (f"timed region = {args.steps} replays of the captured step; per-kernel durations from {args.steps} "
                      "eagerly launched, HIP-event instrumented steps of the same kernels right after it")
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -487,7 +490,7 @@ def main():
         if roof_note and roof is not None:
             roof["timing"] = roof_note
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -264,7 +264,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("SPARCH_DP_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ  # one-rank rehearsal on RCCL
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # SPARCH_DIST_BACKEND=gloo: rehearsal of the multi-process path without RCCL
