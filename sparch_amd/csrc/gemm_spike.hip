@@ -137,19 +137,44 @@ __device__ __forceinline__ f32x4 ld16(const void* q) {
     if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
     else return *reinterpret_cast<const f32x4*>(q);
 }
+// Which 16-byte piece of a ROW-MAJOR (ROWS x 32) operand tile a thread moves (piece index f = tid + NT * p; PPR = 8
+// pieces per row of fp32 source, 4 of a bf16 plane).  Row-major order (row = f / PPR, piece = f % PPR) makes a wave's
+// LDS stores collide: the images' rows are 80 bytes apart (20 banks, the stride that keeps the fragment reads
+// conflict-free), so four CONSECUTIVE rows wrap the 64 banks and the fourth lands on the first — SQ_LDS_BANK_CONFLICT
+// 29 % of the LDS cycles of the NT kernels, 17 % of dX (profiles/r03_pmc_lds.md).  Rows FOUR apart start 16 banks
+// apart, so the lanes that are served together take rows r, r+4, r+8, r+12: each 16 lanes of a 16-byte store and each
+// 32 lanes of an 8-byte store then cover the 64 banks exactly once — and a row's pieces stay on CONSECUTIVE lanes, so
+// the global loads coalesce as before (the first attempt, sixteen rows per piece column, was conflict-free too and
+// 17 % slower: 16-byte requests to 16 different rows per 16 lanes).
+// MEASURED, NOT KEPT (GEMM_RM_MAP=1 selects it): the conflict counter goes to 0 in every kernel and LDS busy from 43 to
+// 30 % (NT) and 39 to 31 % (dX) — and the products do not get faster (tools/gemm_sweep.py, one call: NT with statistics
+// 389 -> 395 us, dX 793 -> 791, dense NN 759 -> 762).  The LDS port is not what these kernels wait for.
+#ifndef GEMM_RM_MAP
+#define GEMM_RM_MAP 0
+#endif
+template <int PPR>
+__device__ __forceinline__ void rm_piece(int f, int& row, int& kp) {
+#if GEMM_RM_MAP
+    const int l = f & 63;
+    if constexpr (PPR == 4) { row = ((f >> 6) << 4) + (l >> 4) + (((l >> 2) & 3) << 2); kp = l & 3; }
+    else { row = ((f >> 7) << 4) + (((f >> 6) & 1) << 1) + (l >> 5) + (((l >> 3) & 3) << 2); kp = l & 7; }
+#else
+    row = f / PPR; kp = f % PPR;
+#endif
+}
 template <bool KM, int ROWS, int NT, bool STREAM = false>
 __device__ __forceinline__ void load_piece(f32x4& out, int p, bool fast, const float* __restrict__ P, int ld,
                                            int row0, int rows, int k0, int kend, int vec, int tid) {
     constexpr int RQ = ROWS / 4;  // pieces per k row of a KM tile
     const int f = tid + NT * p;
+    int row, k;
+    if constexpr (!KM) { int r_, kp_; rm_piece<8>(f, r_, kp_); row = row0 + r_; k = k0 + (kp_ << 2); }
+    else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 2); }
     if (fast) {
-        if constexpr (!KM) out = ld16<STREAM>(P + (size_t)(row0 + (f >> 3)) * ld + k0 + ((f & 7) << 2));
-        else               out = ld16<STREAM>(P + (size_t)(k0 + f / RQ) * ld + row0 + ((f % RQ) << 2));
+        if constexpr (!KM) out = ld16<STREAM>(P + (size_t)row * ld + k);
+        else               out = ld16<STREAM>(P + (size_t)k * ld + row);
         return;
     }
-    int row, k;
-    if constexpr (!KM) { row = row0 + (f >> 3); k = k0 + ((f & 7) << 2); }
-    else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 2); }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if constexpr (!KM) {
         if (row < rows) {
@@ -185,7 +210,7 @@ __device__ __forceinline__ void load_piece16(f32x4& out, int p, bool fast, const
     constexpr int RQ = ROWS / 8;  // pieces per k row of a KM tile
     const int f = tid + NT * p;
     int row, k;
-    if constexpr (!KM) { row = row0 + (f >> 2); k = k0 + ((f & 3) << 3); }
+    if constexpr (!KM) { int r_, kp_; rm_piece<4>(f, r_, kp_); row = row0 + r_; k = k0 + (kp_ << 3); }
     else               { k = k0 + f / RQ; row = row0 + ((f % RQ) << 3); }
     const unsigned short* q = KM ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
     if (fast) { out = ld16<STREAM>(q); return; }
@@ -207,7 +232,7 @@ __device__ __forceinline__ void store_piece16(const f32x4& r, int p, unsigned sh
     constexpr int RQ = ROWS / 8;
     const int f = tid + NT * p;
     int off;  // bf16 elements, 16-byte aligned (80-byte KC rows, 16-byte multiples for KM rows)
-    if constexpr (!KM) off = (f >> 2) * KC_ROW + ((f & 3) << 3);
+    if constexpr (!KM) { int r_, kp_; rm_piece<4>(f, r_, kp_); off = r_ * KC_ROW + (kp_ << 3); }
     else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 3);
     *reinterpret_cast<f32x4*>(S + off) = r;
 }
@@ -238,7 +263,7 @@ __device__ __forceinline__ void store_piece(const f32x4& r, int p, unsigned shor
     constexpr int PLANE = plane_elems<KM, ROWS>();
     const int f = tid + NT * p;
     int off;  // in bf16 elements, 8-byte aligned
-    if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
+    if constexpr (!KM) { int r_, kp_; rm_piece<8>(f, r_, kp_); off = r_ * KC_ROW + (kp_ << 2); }
     else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
     if constexpr (SPIKE) {
         // e_exact (uniform): the values are bf16-exact and their bf16 form is the upper half of the fp32
@@ -285,7 +310,7 @@ __device__ __forceinline__ void store_piece_rne1(const f32x4& r, int p, unsigned
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     const int f = tid + NT * p;
     int off;
-    if constexpr (!KM) off = (f >> 3) * KC_ROW + ((f & 7) << 2);
+    if constexpr (!KM) { int r_, kp_; rm_piece<8>(f, r_, kp_); off = r_ * KC_ROW + (kp_ << 2); }
     else               off = (f / RQ) * km_row<ROWS>() + ((f % RQ) << 2);
     u32x2 w;
     w.x = __builtin_bit_cast(unsigned, bf16x2{(__bf16)r.x, (__bf16)r.y});
